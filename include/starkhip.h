@@ -1,0 +1,150 @@
+/*
+ * libstarkhip — C ABI of the MI355X (gfx950) hot path of a MiMC STARK verifier:
+ * the radix-2 NTT / inverse NTT over p = 2^256 - 351*2^32 + 1 and batched BLAKE2s
+ * Merkle-branch verification.
+ *
+ * The entry points are what a host-language binding of the reference crate would bind in
+ * place of the bodies of `fft::fft_inv` (reference src/fft.rs:64), `ProofBranch::verify`
+ * (src/merkle_tree.rs:119) and `MultiProof::verify` (src/merkle_tree.rs:25); their callers
+ * are src/lib.rs:58,68,125,158,159.
+ *
+ * Conventions
+ *   - A field element is 8 little-endian uint32 limbs (32 bytes). Inputs may be any 256-bit
+ *     value; outputs are always the canonical residue in [0, p), which is what the reference's
+ *     BigInt arithmetic (`%`, utils::negative_to_positive) yields.
+ *   - Digests, Merkle values and witnesses are opaque bytes, exactly as in the proof file.
+ *   - Every function returns STARK_OK or a negative status; nothing unwinds across the ABI.
+ *     Where the reference panics (bad lengths, a root of unity of the wrong order, a branch
+ *     with no witnesses) the call returns STARK_ERR_INVALID and writes nothing. A Merkle
+ *     mismatch is not an error here: it is reported per branch in `accept[]`; the binding
+ *     re-creates the reference's panic / None from that.
+ *   - Host-pointer entry points copy in, run on the context's stream, copy out, and return
+ *     after the stream has drained. The `_dev` variants take device pointers (any allocator:
+ *     hipMalloc, a torch tensor's data_ptr) and a hipStream_t passed as void*; they only
+ *     enqueue work and do not synchronise.
+ *   - A context is bound to one device and is not thread-safe; use one per host thread.
+ */
+#ifndef STARKHIP_H
+#define STARKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STARK_OK 0
+#define STARK_ERR_INVALID (-1)     /* argument rejected (shapes on which the reference panics) */
+#define STARK_ERR_HIP (-2)         /* a HIP runtime call failed; see stark_last_error */
+#define STARK_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define STARK_ERR_UNSUPPORTED (-4) /* valid request outside what this build implements */
+
+typedef struct stark_ctx stark_ctx;
+
+/* Library version: major*10000 + minor*100 + patch. */
+int stark_version(void);
+
+/* Create / destroy a context on HIP device `device`. */
+int stark_ctx_create(int device, stark_ctx** out);
+void stark_ctx_destroy(stark_ctx* ctx);
+
+/* Text of the last failure on this context (never NULL). */
+const char* stark_last_error(const stark_ctx* ctx);
+
+/* The context's own stream (a hipStream_t), for callers that queue work beside `_dev` calls. */
+void* stark_ctx_stream(stark_ctx* ctx);
+
+/* Block until everything queued on the context's stream has finished. */
+int stark_ctx_synchronize(stark_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------
+ * NTT — replaces the body of fft::fft_inv (reference src/fft.rs:64-86) and its private
+ * helpers _fft (:37-61) and simple_ft (:18-35).
+ * ------------------------------------------------------------------------------------- */
+
+/*
+ * fft_inv(v, root_of_unity, modulus) -> Vec<BigInt>     (reference src/fft.rs:64)
+ *   out[i] = n^-1 * sum_j v[j] * root^(-i*j) mod p,  n = number of elements.
+ * `modulus` must be p (the only modulus the reference is ever called with, src/lib.rs:29,125).
+ * Requires n to be a power of two and `root_of_unity` to have multiplicative order exactly n:
+ * for any other input the reference indexes out of bounds and panics -> STARK_ERR_INVALID.
+ * `v` and `out` are host arrays of n*8 limbs and may alias.
+ */
+int stark_fft_inv(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8],
+                  const uint32_t modulus[8], uint32_t* out);
+
+/*
+ * Forward transform out[i] = sum_j v[j] * root^(i*j) mod p. The reference has no public
+ * wrapper for it; it is _fft (src/fft.rs:37) applied to the root table [root^0 .. root^(n-1)].
+ * Same argument rules as stark_fft_inv.
+ */
+int stark_fft(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8],
+              const uint32_t modulus[8], uint32_t* out);
+
+/*
+ * Batched transform of `batch` polynomials of 2^log_n elements each, stored back to back
+ * (polynomial b occupies limbs [b*2^log_n*8, (b+1)*2^log_n*8)). inverse != 0 selects fft_inv
+ * semantics (inverse root and n^-1 scaling), inverse == 0 the forward transform.
+ * Host version: in place on `limbs`.
+ */
+int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch,
+                    const uint32_t root_of_unity[8], int inverse);
+
+/*
+ * Device version: d_in and d_out are device pointers to batch*2^log_n*32 bytes, 16-byte
+ * aligned; they may be equal (in place). Work is queued on `stream` (NULL = the context's
+ * stream). Multi-pass sizes use a scratch buffer owned by the context, so calls on one
+ * context must not overlap on different streams. Twiddle tables are built on first use of a
+ * (log_n, root, direction) triple and cached in the context.
+ */
+int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
+                        const uint32_t root_of_unity[8], int inverse, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Merkle — replaces the bodies of ProofBranch::verify (reference src/merkle_tree.rs:119-171)
+ * and the loop of MultiProof::verify (src/merkle_tree.rs:25-44).
+ * ------------------------------------------------------------------------------------- */
+
+/*
+ * Verify n branches that share one shape (value_size bytes per value, num_witnesses
+ * witnesses per branch); the binding groups a MultiProof's branches by shape.
+ *   values, siblings : [n][value_size]      ProofBranch.value / .sibling_value
+ *   witnesses        : [num_witnesses][n][32]   level-major; level 0 is ProofBranch.witnesses[0]
+ *   indices          : [n]                  the `a` passed to ProofBranch::verify (unpermuted)
+ *   roots            : [num_roots][32]; root_ids : [n] indices into roots, or NULL = roots[0]
+ *   accept           : [n] out, 1 = recomputed root equals the branch's root, 0 = mismatch
+ *   digests          : [n][32] out, the recomputed roots; may be NULL
+ * STARK_ERR_INVALID where the reference panics before hashing: num_witnesses == 0 (division
+ * by zero at :113-114), value_size < 32 (slice at :133), and for num_witnesses > 30 (the
+ * reference's 2u32.pow overflows), or a root id >= num_roots.
+ */
+int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8_t* siblings,
+                              uint32_t value_size, const uint8_t* witnesses, uint32_t num_witnesses,
+                              const uint32_t* indices, const uint8_t* roots, uint32_t num_roots,
+                              const uint32_t* root_ids, size_t n, uint8_t* accept, uint8_t* digests);
+
+/* Device version: same layout, device pointers (values/siblings/witnesses/roots/digests
+ * 16-byte aligned), queued on `stream` (NULL = the context's stream). root ids are not range
+ * checked here. */
+int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const void* d_siblings,
+                                  uint32_t value_size, const void* d_witnesses, uint32_t num_witnesses,
+                                  const void* d_indices, const void* d_roots, const void* d_root_ids,
+                                  size_t n, void* d_accept, void* d_digests, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Test and benchmark support (no counterpart in the reference).
+ * ------------------------------------------------------------------------------------- */
+
+/* Element-wise field arithmetic on host arrays of n*8 limbs: op 0 = a+b, 1 = a-b, 2 = a*b,
+ * 3 = canonical form of a (b ignored, may be NULL). Exercises the device arithmetic alone. */
+int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n);
+
+/* Fill a device buffer with n canonical field elements drawn from SplitMix64(seed): element i
+ * takes draws 4i..4i+3 as its four little-endian 64-bit words, reduced mod p. */
+int stark_fill_random_field_dev(stark_ctx* ctx, void* d_out, size_t n, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARKHIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libstarkhip.so (the C ABI declared in include/starkhip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  ``import torch`` happens first when torch is installed so that this process ends up
+with a single HIP runtime (torch bundles its own libamdhip64 under the same soname).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+try:  # plumbing only: device tensors and torch.distributed for the benchmarks
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+
+STARK_OK = 0
+STARK_ERR_INVALID = -1
+STARK_ERR_HIP = -2
+STARK_ERR_NOMEM = -3
+STARK_ERR_UNSUPPORTED = -4
+
+EXPORTS = [
+    "stark_version", "stark_ctx_create", "stark_ctx_destroy", "stark_last_error", "stark_ctx_stream",
+    "stark_ctx_synchronize", "stark_fft_inv", "stark_fft", "stark_ntt_batch", "stark_ntt_batch_dev",
+    "stark_merkle_verify_batch", "stark_merkle_verify_batch_dev", "stark_field_op",
+    "stark_fill_random_field_dev",
+]
+
+
+class StarkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libstarkhip error {code}: {message}")
+        self.code = code
+
+
+class InvalidArgument(StarkError, ValueError):
+    """The call was rejected (shapes on which the reference implementation panics)."""
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C stark_verifier_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    L.stark_version.restype = i32
+    L.stark_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.stark_ctx_create.restype = i32
+    L.stark_ctx_destroy.argtypes = [vp]
+    L.stark_ctx_destroy.restype = None
+    L.stark_last_error.argtypes = [vp]
+    L.stark_last_error.restype = ctypes.c_char_p
+    L.stark_ctx_stream.argtypes = [vp]
+    L.stark_ctx_stream.restype = vp
+    L.stark_ctx_synchronize.argtypes = [vp]
+    L.stark_ctx_synchronize.restype = i32
+    L.stark_fft_inv.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.stark_fft_inv.restype = i32
+    L.stark_fft.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.stark_fft.restype = i32
+    L.stark_ntt_batch.argtypes = [vp, vp, ctypes.c_uint, sz, vp, i32]
+    L.stark_ntt_batch.restype = i32
+    L.stark_ntt_batch_dev.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
+    L.stark_ntt_batch_dev.restype = i32
+    L.stark_merkle_verify_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, u32, vp, sz, vp, vp]
+    L.stark_merkle_verify_batch.restype = i32
+    L.stark_merkle_verify_batch_dev.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, vp, sz, vp, vp, vp]
+    L.stark_merkle_verify_batch_dev.restype = i32
+    L.stark_field_op.argtypes = [vp, i32, vp, vp, vp, sz]
+    L.stark_field_op.restype = i32
+    L.stark_fill_random_field_dev.argtypes = [vp, vp, sz, u64, vp]
+    L.stark_fill_random_field_dev.restype = i32
+    _lib = L
+    return L
+
+
+class Context:
+    """Owns one ``stark_ctx`` (device buffers, stream, cached twiddle tables)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        rc = self._lib.stark_ctx_create(device, ctypes.byref(h))
+        if rc != STARK_OK:
+            raise StarkError(rc, f"stark_ctx_create(device={device}) failed (is a HIP device visible?)")
+        self._h = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc == STARK_OK:
+            return
+        msg = self._lib.stark_last_error(self._h).decode("utf-8", "replace")
+        if rc == STARK_ERR_INVALID:
+            raise InvalidArgument(rc, msg)
+        raise StarkError(rc, msg)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def lib(self):
+        return self._lib
+
+    @property
+    def stream(self) -> int:
+        return self._lib.stark_ctx_stream(self._h) or 0
+
+    def synchronize(self):
+        self.check(self._lib.stark_ctx_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stark_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

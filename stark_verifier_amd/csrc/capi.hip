@@ -1,0 +1,604 @@
+// C ABI of libstarkhip (see include/starkhip.h): context, transform plans, host-buffer staging.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/starkhip.h"
+#include "host_field.hpp"
+#include "internal.hpp"
+
+using namespace starkhip;
+using hostfe::U256;
+
+namespace {
+
+struct PassPlan {
+    int log_t = 0;
+    NttPassArgs args = {};  // in/out filled per call
+    unsigned tiles = 0;
+    bool poly_in_grid = false;  // grid.y = polynomials (multi-pass) or folded into tiles
+};
+
+struct NttPlan {
+    unsigned log_n = 0;
+    U256 root = {};
+    bool inverse = false;
+    std::vector<PassPlan> passes;
+    std::vector<void*> tables;
+    bool tiny = false;  // n <= 2
+    uint32_t scale[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    int has_scale = 0;
+};
+
+}  // namespace
+
+struct stark_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<std::unique_ptr<NttPlan>> plans;
+    void* scratch = nullptr;  // multi-pass intermediate
+    size_t scratch_bytes = 0;
+    void* io = nullptr;  // staging for the host-pointer entry points
+    size_t io_bytes = 0;
+    size_t chunk_bytes = (size_t)128 << 20;
+};
+
+namespace {
+
+int fail(stark_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? STARK_ERR_NOMEM : STARK_ERR_HIP,       \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure_buffer(stark_ctx* ctx, void** buf, size_t* have, size_t need) {
+    if (*have >= need) return STARK_OK;
+    if (*buf) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(buf, need));
+    *have = need;
+    return STARK_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+// How a transform of 2^log_n points is cut into passes of at most 2^12 points.
+std::vector<int> choose_split(unsigned log_n) {
+    const char* s = getenv("STARKHIP_SPLIT");  // e.g. "8,8,8": tuning aid, must sum to log_n
+    if (s && *s) {
+        std::vector<int> v;
+        int sum = 0;
+        for (const char* p = s; *p;) {
+            int x = atoi(p);
+            if (x >= 2 && x <= 12) {
+                v.push_back(x);
+                sum += x;
+            }
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        if (sum == (int)log_n && v.size() >= 1 && v.size() <= 3) return v;
+    }
+    if (log_n <= 12) return {(int)log_n};
+    if (log_n <= 24) return {(int)(log_n + 1) / 2, (int)log_n / 2};
+    int a = ((int)log_n + 2) / 3, b = ((int)log_n - a + 1) / 2;
+    return {a, b, (int)log_n - a - b};
+}
+
+// Tiles per workgroup (log2): as many as fit the thread and LDS budget and the extent.
+int choose_log_c(int log_t, unsigned log_extent, int target_threads) {
+    int log_q = log_t - 2;
+    int log_c = 0;
+    int lim = env_int("STARKHIP_LDS_LIMIT", 80 * 1024);
+    while (log_c + 1 <= (int)log_extent && (1 << (log_q + log_c + 1)) <= target_threads &&
+           (int)ntt_pass_lds_bytes(log_t, log_c + 1) <= lim)
+        log_c++;
+    return log_c;
+}
+
+int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, uint64_t row_len, const U256& scale,
+               uint32_t** out) {
+    uint32_t pw[64 * 8];
+    U256 b = base;
+    for (int k = 0; k < 64; k++) {
+        hostfe::to_limbs(b, pw + 8 * k);
+        b = hostfe::mul(b, b);
+    }
+    void* d_pw = nullptr;
+    void* d_tab = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_pw, sizeof pw));
+    hipError_t e = hipMalloc(&d_tab, count * 32);
+    if (e != hipSuccess) {
+        (void)hipFree(d_pw);
+        return fail(ctx, STARK_ERR_NOMEM, "twiddle table of %zu bytes: %s", count * 32, hipGetErrorString(e));
+    }
+    plan->tables.push_back(d_tab);
+    uint32_t sc[8];
+    hostfe::to_limbs(scale, sc);
+    e = hipMemcpyAsync(d_pw, pw, sizeof pw, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_fill_powers((uint32_t*)d_tab, count, row_len, (const uint32_t*)d_pw, sc, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_pw);
+    if (e != hipSuccess) return fail(ctx, STARK_ERR_HIP, "twiddle table build: %s", hipGetErrorString(e));
+    *out = (uint32_t*)d_tab;
+    return STARK_OK;
+}
+
+void free_plan(NttPlan* p) {
+    for (void* t : p->tables) (void)hipFree(t);
+    p->tables.clear();
+}
+
+// `root` has order exactly 2^log_n (checked by the caller).
+int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, NttPlan** out) {
+    std::unique_ptr<NttPlan> plan(new NttPlan);
+    plan->log_n = log_n;
+    plan->root = root;
+    plan->inverse = inverse;
+    const uint64_t n = (uint64_t)1 << log_n;
+    // the transform's own root and the factor applied to every output
+    U256 w = inverse ? hostfe::pow_u64(root, n - 1) : root;  // root^-1 = root^(n-1)
+    U256 scale = inverse ? hostfe::inverse(hostfe::from_u64(n)) : hostfe::from_u64(1);
+    hostfe::to_limbs(scale, plan->scale);
+    plan->has_scale = inverse && log_n > 0;
+    const U256 one = hostfe::from_u64(1);
+    int rc;
+
+    if (log_n <= 1) {
+        plan->tiny = true;
+        *out = plan.get();
+        ctx->plans.push_back(std::move(plan));
+        return STARK_OK;
+    }
+
+    std::vector<int> split = choose_split(log_n);
+    const int target_threads = env_int("STARKHIP_THREADS", 512);
+    const int forced_log_c = env_int("STARKHIP_LOGC", -1);
+    auto pick_c = [&](int log_t, unsigned log_extent) {
+        int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads);
+        if (forced_log_c >= 0 && forced_log_c <= (int)log_extent && (1 << (log_t - 2 + forced_log_c)) <= 1024 &&
+            ntt_pass_lds_bytes(log_t, forced_log_c) <= 160 * 1024)
+            lc = forced_log_c;
+        return lc;
+    };
+
+    if (split.size() == 1) {
+        PassPlan p;
+        p.log_t = (int)log_n;
+        int log_c = 0;  // polynomials per workgroup: fill 256 lanes
+        while ((1 << (p.log_t - 2 + log_c)) < 256) log_c++;
+        NttPassArgs& a = p.args;
+        a.log_c = log_c;
+        a.dsh = 31;
+        a.dmask = 0xFFFFFFFFu;
+        a.inB = a.outB = n << log_c;
+        a.inC = a.outC = n;
+        a.inS = a.outS = 1;
+        a.load_cfast = a.store_cfast = 0;
+        a.canon_in = 1;
+        a.has_scale = plan->has_scale;
+        memcpy(a.scale, plan->scale, sizeof a.scale);
+        uint32_t* W;
+        if ((rc = make_table(ctx, plan.get(), w, n, 0, one, &W)) != STARK_OK) {
+            free_plan(plan.get());
+            return rc;
+        }
+        a.W = W;
+        plan->passes.push_back(p);
+    } else {
+        // n = n1 * m, m = n2 (* n3)
+        const int l1 = split[0];
+        const unsigned lm = log_n - l1;
+        const uint64_t n1 = (uint64_t)1 << l1, m = (uint64_t)1 << lm;
+        uint32_t *W1, *TW1;
+        U256 w1 = hostfe::pow_u64(w, m);  // order n1
+        if ((rc = make_table(ctx, plan.get(), w1, n1, 0, one, &W1)) != STARK_OK ||
+            (rc = make_table(ctx, plan.get(), w, n, m, scale, &TW1)) != STARK_OK) {
+            free_plan(plan.get());
+            return rc;
+        }
+        {
+            PassPlan p;
+            p.log_t = l1;
+            p.poly_in_grid = true;
+            NttPassArgs& a = p.args;
+            a.log_c = pick_c(l1, lm);
+            const uint64_t C = (uint64_t)1 << a.log_c;
+            a.dsh = 31;
+            a.dmask = 0xFFFFFFFFu;
+            a.poly_stride = n;
+            a.inB = a.outB = a.twB = C;
+            a.inC = a.outC = a.twC = 1;
+            a.inS = a.outS = a.twS = m;
+            a.c_limit = ~0ull;
+            a.load_cfast = a.store_cfast = 1;
+            a.canon_in = 1;
+            a.W = W1;
+            a.TW = TW1;
+            p.tiles = (unsigned)(m >> a.log_c);
+            plan->passes.push_back(p);
+        }
+        if (split.size() == 2) {
+            const int l2 = split[1];
+            uint32_t* W2;
+            U256 w2 = hostfe::pow_u64(w, n1);  // order m
+            if ((rc = make_table(ctx, plan.get(), w2, m, 0, one, &W2)) != STARK_OK) {
+                free_plan(plan.get());
+                return rc;
+            }
+            PassPlan p;
+            p.log_t = l2;
+            p.poly_in_grid = true;
+            NttPassArgs& a = p.args;
+            a.log_c = pick_c(l2, l1);
+            const uint64_t C = (uint64_t)1 << a.log_c;
+            a.dsh = 31;
+            a.dmask = 0xFFFFFFFFu;
+            a.poly_stride = n;
+            a.inB = C * m;
+            a.inC = m;
+            a.inS = 1;
+            a.outB = C;
+            a.outC = 1;
+            a.outS = n1;
+            a.c_limit = ~0ull;
+            a.load_cfast = 0;
+            a.store_cfast = 1;
+            a.W = W2;
+            p.tiles = (unsigned)(n1 >> a.log_c);
+            plan->passes.push_back(p);
+        } else {
+            const int l2 = split[1], l3 = split[2];
+            const uint64_t n2 = (uint64_t)1 << l2, n3 = (uint64_t)1 << l3;
+            uint32_t *W2, *W3, *TW2;
+            U256 wm = hostfe::pow_u64(w, n1);      // order m
+            U256 w2 = hostfe::pow_u64(wm, n3);     // order n2
+            U256 w3 = hostfe::pow_u64(wm, n2);     // order n3
+            if ((rc = make_table(ctx, plan.get(), w2, n2, 0, one, &W2)) != STARK_OK ||
+                (rc = make_table(ctx, plan.get(), w3, n3, 0, one, &W3)) != STARK_OK ||
+                (rc = make_table(ctx, plan.get(), wm, m, n3, one, &TW2)) != STARK_OK) {
+                free_plan(plan.get());
+                return rc;
+            }
+            {
+                PassPlan p;
+                p.log_t = l2;
+                p.poly_in_grid = true;
+                NttPassArgs& a = p.args;
+                a.log_c = pick_c(l2, (unsigned)l3);
+                const uint64_t C = (uint64_t)1 << a.log_c;
+                a.dsh = (uint32_t)(l3 - (int)a.log_c);  // tiles per row = n3 / C
+                a.dmask = (uint32_t)((n3 >> a.log_c) - 1);
+                a.poly_stride = n;
+                a.inA = a.outA = m;
+                a.inB = a.outB = a.twB = C;
+                a.inC = a.outC = a.twC = 1;
+                a.inS = a.outS = a.twS = n3;
+                a.c_limit = ~0ull;
+                a.load_cfast = a.store_cfast = 1;
+                a.W = W2;
+                a.TW = TW2;
+                p.tiles = (unsigned)(n1 * (n3 >> a.log_c));
+                plan->passes.push_back(p);
+            }
+            {
+                PassPlan p;
+                p.log_t = l3;
+                p.poly_in_grid = true;
+                NttPassArgs& a = p.args;
+                a.log_c = pick_c(l3, (unsigned)l1);
+                const uint64_t C = (uint64_t)1 << a.log_c;
+                a.dsh = (uint32_t)l2;
+                a.dmask = (uint32_t)(n2 - 1);
+                a.poly_stride = n;
+                a.inA = C * m;
+                a.inB = n3;
+                a.inC = m;
+                a.inS = 1;
+                a.outA = C;
+                a.outB = n1;
+                a.outC = 1;
+                a.outS = n1 * n2;
+                a.c_limit = ~0ull;
+                a.load_cfast = 0;
+                a.store_cfast = 1;
+                a.W = W3;
+                p.tiles = (unsigned)((n1 >> a.log_c) * n2);
+                plan->passes.push_back(p);
+            }
+        }
+    }
+    *out = plan.get();
+    ctx->plans.push_back(std::move(plan));
+    return STARK_OK;
+}
+
+int get_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, NttPlan** out) {
+    for (auto& p : ctx->plans)
+        if (p->log_n == log_n && p->inverse == inverse && hostfe::eq(p->root, root)) {
+            *out = p.get();
+            return STARK_OK;
+        }
+    return build_plan(ctx, log_n, root, inverse, out);
+}
+
+// root^n == 1 and, for n > 1, root^(n/2) != 1  (n = 2^log_n): the order is exactly n
+bool has_order(const U256& root, unsigned log_n) {
+    U256 x = root;
+    const U256 one = hostfe::from_u64(1);
+    for (unsigned i = 0; i < log_n; i++) {
+        if (i + 1 == log_n && hostfe::eq(x, one)) return false;
+        x = hostfe::mul(x, x);
+    }
+    return hostfe::eq(x, one);
+}
+
+int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_out, size_t batch, hipStream_t stream) {
+    const uint64_t n = (uint64_t)1 << plan->log_n;
+    if (batch == 0) return STARK_OK;
+    if (plan->tiny) {
+        HIP_TRY(ctx, launch_ntt_tiny(d_in, d_out, (int)plan->log_n, batch, plan->scale, plan->has_scale, stream));
+        return STARK_OK;
+    }
+    if (plan->passes.size() == 1) {
+        PassPlan& p = plan->passes[0];
+        const uint64_t C = (uint64_t)1 << p.args.log_c;
+        // at most 2^31 tiles per launch
+        const size_t max_polys = ((size_t)1 << 30) * C;
+        for (size_t done = 0; done < batch; done += max_polys) {
+            size_t cnt = batch - done < max_polys ? batch - done : max_polys;
+            NttPassArgs a = p.args;
+            a.in = d_in + 8 * n * done;
+            a.out = d_out + 8 * n * done;
+            a.c_limit = cnt;
+            HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
+        }
+        return STARK_OK;
+    }
+    // multi-pass: first pass into scratch, middle pass in place there, last pass to d_out
+    size_t chunk = ctx->chunk_bytes / (n * 32);
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if (chunk > 65535) chunk = 65535;
+    int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, chunk * n * 32);
+    if (rc != STARK_OK) return rc;
+    uint32_t* tmp = (uint32_t*)ctx->scratch;
+    for (size_t done = 0; done < batch; done += chunk) {
+        size_t cnt = batch - done < chunk ? batch - done : chunk;
+        for (size_t k = 0; k < plan->passes.size(); k++) {
+            PassPlan& p = plan->passes[k];
+            NttPassArgs a = p.args;
+            a.in = k == 0 ? d_in + 8 * n * done : tmp;
+            a.out = k + 1 == plan->passes.size() ? d_out + 8 * n * done : tmp;
+            HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
+        }
+    }
+    return STARK_OK;
+}
+
+int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch, const uint32_t root[8],
+               int inverse, hipStream_t stream) {
+    if (log_n > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 30", log_n);
+    U256 r = hostfe::canon(hostfe::from_limbs(root));
+    if (!has_order(r, log_n))
+        return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    NttPlan* plan;
+    int rc = get_plan(ctx, log_n, r, inverse != 0, &plan);
+    if (rc != STARK_OK) return rc;
+    return run_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_out, batch, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int stark_version(void) { return 100; }
+
+int stark_ctx_create(int device, stark_ctx** out) {
+    if (!out) return STARK_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return STARK_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return STARK_ERR_HIP;
+    stark_ctx* ctx = new stark_ctx;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return STARK_ERR_HIP;
+    }
+    const char* cb = getenv("STARKHIP_CHUNK_MB");
+    if (cb && atoi(cb) > 0) ctx->chunk_bytes = (size_t)atoi(cb) << 20;
+    *out = ctx;
+    return STARK_OK;
+}
+
+void stark_ctx_destroy(stark_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->plans) free_plan(p.get());
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->io) (void)hipFree(ctx->io);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* stark_last_error(const stark_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void* stark_ctx_stream(stark_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int stark_ctx_synchronize(stark_ctx* ctx) {
+    if (!ctx) return STARK_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
+                        const uint32_t root_of_unity[8], int inverse, void* stream) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || (batch && (!d_in || !d_out))) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ntt_common(ctx, d_in, d_out, log_n, batch, root_of_unity, inverse, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch, const uint32_t root_of_unity[8],
+                    int inverse) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || (batch && !limbs)) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_n > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 30", log_n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // validate before touching the device so that a rejected call writes nothing
+    U256 r = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(r, log_n)) return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    if (batch == 0) return STARK_OK;
+    size_t bytes = (batch << log_n) * 32;
+    int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, bytes);
+    if (rc != STARK_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->io, limbs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_common(ctx, ctx->io, ctx->io, log_n, batch, root_of_unity, inverse, ctx->stream);
+    if (rc != STARK_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(limbs, ctx->io, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+static int fft_host(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root[8], const uint32_t modulus[8],
+                    uint32_t* out, int inverse) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!v || !root || !modulus || !out) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (!hostfe::eq(hostfe::from_limbs(modulus), hostfe::MODULUS))
+        return fail(ctx, STARK_ERR_UNSUPPORTED, "modulus is not 2^256 - 351*2^32 + 1");
+    if (n == 0 || (n & (n - 1))) return fail(ctx, STARK_ERR_INVALID, "length %zu is not a power of two", n);
+    unsigned log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    if (out != v) memmove(out, v, n * 32);
+    // stark_ntt_batch validates the root before it writes; on rejection `out` holds the input copy
+    return stark_ntt_batch(ctx, out, log_n, 1, root, inverse);
+}
+
+int stark_fft_inv(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8],
+                  const uint32_t modulus[8], uint32_t* out) {
+    return fft_host(ctx, v, n, root_of_unity, modulus, out, 1);
+}
+
+int stark_fft(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8], const uint32_t modulus[8],
+              uint32_t* out) {
+    return fft_host(ctx, v, n, root_of_unity, modulus, out, 0);
+}
+
+int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const void* d_siblings, uint32_t value_size,
+                                  const void* d_witnesses, uint32_t num_witnesses, const void* d_indices,
+                                  const void* d_roots, const void* d_root_ids, size_t n, void* d_accept,
+                                  void* d_digests, void* stream) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (num_witnesses < 1 || num_witnesses > 30)
+        return fail(ctx, STARK_ERR_INVALID, "num_witnesses %u outside 1..30", num_witnesses);
+    if (value_size < 32) return fail(ctx, STARK_ERR_INVALID, "value_size %u below 32", value_size);
+    if (n == 0) return STARK_OK;
+    if (!d_values || !d_siblings || !d_witnesses || !d_indices || !d_roots || !d_accept)
+        return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (n > ((size_t)1 << 31) * 256) return fail(ctx, STARK_ERR_UNSUPPORTED, "too many branches in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_merkle_verify((const uint8_t*)d_values, (const uint8_t*)d_siblings, value_size,
+                                      (const uint8_t*)d_witnesses, num_witnesses, (const uint32_t*)d_indices,
+                                      (const uint8_t*)d_roots, (const uint32_t*)d_root_ids, n, (uint8_t*)d_accept,
+                                      (uint8_t*)d_digests, stream ? (hipStream_t)stream : ctx->stream));
+    return STARK_OK;
+}
+
+int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
+                              const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
+                              const uint8_t* roots, uint32_t num_roots, const uint32_t* root_ids, size_t n,
+                              uint8_t* accept, uint8_t* digests) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (num_witnesses < 1 || num_witnesses > 30)
+        return fail(ctx, STARK_ERR_INVALID, "num_witnesses %u outside 1..30", num_witnesses);
+    if (value_size < 32) return fail(ctx, STARK_ERR_INVALID, "value_size %u below 32", value_size);
+    if (n == 0) return STARK_OK;
+    if (!values || !siblings || !witnesses || !indices || !roots || !accept || num_roots == 0)
+        return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (root_ids)
+        for (size_t i = 0; i < n; i++)
+            if (root_ids[i] >= num_roots) return fail(ctx, STARK_ERR_INVALID, "root id %u out of range", root_ids[i]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // one staging allocation, every section 256-byte aligned
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t sz_val = al(n * value_size), sz_wit = al((size_t)num_witnesses * n * 32), sz_idx = al(n * 4);
+    const size_t sz_roots = al((size_t)num_roots * 32), sz_acc = al(n), sz_dig = al(n * 32);
+    size_t total = 2 * sz_val + sz_wit + 2 * sz_idx + sz_roots + sz_acc + sz_dig;
+    int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, total);
+    if (rc != STARK_OK) return rc;
+    uint8_t* base = (uint8_t*)ctx->io;
+    uint8_t *d_val = base, *d_sib = d_val + sz_val, *d_wit = d_sib + sz_val, *d_idx = d_wit + sz_wit;
+    uint8_t *d_rid = d_idx + sz_idx, *d_roots = d_rid + sz_idx, *d_acc = d_roots + sz_roots, *d_dig = d_acc + sz_acc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d_val, values, n * value_size, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_sib, siblings, n * value_size, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_wit, witnesses, (size_t)num_witnesses * n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, n * 4, hipMemcpyHostToDevice, s));
+    if (root_ids) HIP_TRY(ctx, hipMemcpyAsync(d_rid, root_ids, n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_roots, roots, (size_t)num_roots * 32, hipMemcpyHostToDevice, s));
+    rc = stark_merkle_verify_batch_dev(ctx, d_val, d_sib, value_size, d_wit, num_witnesses, d_idx, d_roots,
+                                       root_ids ? d_rid : nullptr, n, d_acc, digests ? d_dig : nullptr, s);
+    if (rc != STARK_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(accept, d_acc, n, hipMemcpyDeviceToHost, s));
+    if (digests) HIP_TRY(ctx, hipMemcpyAsync(digests, d_dig, n * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return STARK_OK;
+}
+
+int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (op < 0 || op > 3) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);
+    if (n == 0) return STARK_OK;
+    if (!a || !r || (op != 3 && !b)) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, 3 * n * 32);
+    if (rc != STARK_OK) return rc;
+    uint32_t *da = (uint32_t*)ctx->io, *db = da + 8 * n, *dr = db + 8 * n;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, s));
+    if (op != 3) HIP_TRY(ctx, hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, launch_field_op(op, da, db, dr, n, s));
+    HIP_TRY(ctx, hipMemcpyAsync(r, dr, n * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return STARK_OK;
+}
+
+int stark_fill_random_field_dev(stark_ctx* ctx, void* d_out, size_t n, uint64_t seed, void* stream) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n && !d_out) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_fill_random_field((uint32_t*)d_out, n, seed, stream ? (hipStream_t)stream : ctx->stream));
+    return STARK_OK;
+}
+
+}  // extern "C"

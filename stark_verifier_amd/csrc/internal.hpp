@@ -1,0 +1,55 @@
+// Internal declarations shared by the HIP translation units of libstarkhip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace starkhip {
+
+// ---- merkle.hip ----
+hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
+                                const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
+                                const uint8_t* roots, const uint32_t* root_ids, size_t n, uint8_t* accept,
+                                uint8_t* digests, hipStream_t stream);
+
+// ---- ntt.hip ----
+// One pass of the multi-pass transform: every workgroup transforms 2^log_c tiles of 2^log_t
+// elements. All offsets are in field elements (32 bytes each).
+//   tile index tau = blockIdx.x, hi = tau >> dsh, lo = tau & dmask, c in [0, 2^log_c)
+//   input  element j of tile (tau, c): in  + poly*poly_stride + hi*inA  + lo*inB  + c*inC  + j*inS
+//   output element k of tile (tau, c): out + poly*poly_stride + hi*outA + lo*outB + c*outC + k*outS
+//   if TW: output k is multiplied by TW[hi*twA + lo*twB + c*twC + k*twS] before the store
+//   tiles with lo*2^log_c + c >= c_limit are skipped (ragged batch in the single-pass case)
+struct NttPassArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    const uint32_t* W;   // [2^log_t] powers of the tile's root of unity
+    const uint32_t* TW;  // inter-pass twiddles (scaled by n^-1 for the inverse), or null
+    uint64_t poly_stride;
+    uint64_t inA, inB, inC, inS;
+    uint64_t outA, outB, outC, outS;
+    uint64_t twA, twB, twC, twS;
+    uint64_t c_limit;
+    uint32_t dsh, dmask;
+    uint32_t log_c;
+    uint32_t load_cfast, store_cfast;  // lane order: tile index fastest (1) or element index fastest (0)
+    uint32_t canon_in;   // inputs may be any 256-bit value: reduce on load (first pass only)
+    uint32_t has_scale;
+    uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)
+};
+
+size_t ntt_pass_lds_bytes(int log_t, int log_c);
+hipError_t launch_ntt_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
+// n = 1 or 2 (no radix-4 round exists): out = transform(in), one lane per polynomial
+hipError_t launch_ntt_tiny(const uint32_t* in, uint32_t* out, int log_n, size_t batch, const uint32_t scale[8],
+                           int has_scale, hipStream_t stream);
+// out[i] = scale * base^e(i), e(i) = i (row_len == 0) or (i / row_len) * (i % row_len);
+// pw[k] = base^(2^k), k < 64
+hipError_t launch_fill_powers(uint32_t* out, size_t count, uint64_t row_len, const uint32_t* pw_dev,
+                              const uint32_t scale[8], hipStream_t stream);
+// element-wise field op for tests: 0 add, 1 sub, 2 mul, 3 canon(a)
+hipError_t launch_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n, hipStream_t stream);
+// synthetic canonical field elements from SplitMix64(seed), 4 draws per element
+hipError_t launch_fill_random_field(uint32_t* out, size_t n, uint64_t seed, hipStream_t stream);
+
+}  // namespace starkhip
