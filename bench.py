@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path: 2^20-point 256-bit NTTs/s and Merkle branch verifications/s.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (under torch.distributed.run for N > 1). The workload is partitioned, not
+exchanged: every rank transforms its own batch of polynomials and verifies its own branches, so
+there is no data-path collective ("weak" scaling); torch.distributed is used only for the
+barriers and the max-over-ranks of the timed region.
+
+A step of the headline region is one forward NTT of `--ntt-batch` polynomials of 2^20 points,
+inputs and outputs resident in HBM. A second region, timed the same way, verifies
+`--merkle-n` depth-20 branches per step. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import stark_verifier_amd as sv  # noqa: E402
+
+P = 2**256 - 351 * 2**32 + 1
+SEED = 0x5354524B  # "STRK"
+# algorithmic work per unit
+OPS_PER_BUTTERFLY = 152          # 128 IMAD32 + 24 add/sub-with-carry
+OPS_PER_COMPRESSION = 1136       # 80 G x 14 + 16 finalisation xors
+PEAK_VALU_TOPS = 78.6            # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, full-rate 32-bit VALU
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_merkle_case(n: int, depth: int, seed: int, corrupt_every: int = 100):
+    """One real BLAKE2s tree with 2^depth 32-byte leaves (hashlib) and n uniformly random queries
+    against it; every `corrupt_every`-th branch gets one flipped witness bit (expected reject)."""
+    w = depth - 1
+    L = 1 << depth
+    rng = np.random.default_rng(seed)
+    nodes = np.zeros((2 * L, 32), dtype=np.uint8)
+    nodes[L:] = rng.integers(0, 256, size=(L, 32), dtype=np.uint8)
+    flat = nodes.reshape(-1)
+    h = hashlib.blake2s
+    mv = memoryview(flat)
+    for i in range(L - 1, 0, -1):
+        flat[32 * i:32 * i + 32] = np.frombuffer(h(mv[64 * i:64 * i + 64]).digest(), dtype=np.uint8)
+    idx = rng.integers(0, L, size=n, dtype=np.uint32)
+    ld4 = L // 4
+    pos = (idx // ld4 + 4 * (idx % ld4)).astype(np.int64)  # permute_4_index, src/merkle_tree.rs:112-116
+    values, sibs = nodes[L + pos], nodes[L + (pos ^ 1)]
+    wit = np.stack([nodes[((L + pos) >> (k + 1)) ^ 1] for k in range(w)])
+    expect = np.ones(n, dtype=np.uint8)
+    if corrupt_every:
+        bad = np.arange(0, n, corrupt_every)
+        wit[rng.integers(0, w, size=bad.size), bad, rng.integers(0, 32, size=bad.size)] ^= 0x04
+        expect[bad] = 0
+    return values, sibs, np.ascontiguousarray(wit), idx, nodes[1].copy(), expect
+
+
+def timed_region(fn, steps: int, warmup: int, world: int, device):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
+    Returns (seconds, max over ranks) and the mean per-step device time from events."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if steps else 0.0
+    return dt, dev_ms
+
+
+def cpu_baseline(log_n: int, merkle_sample: int, merkle_case):
+    """The CPU oracle (C restatement of the reference's fft.rs / merkle_tree.rs) on one core,
+    on a bounded sample of the same workload."""
+    import oracle  # checker only: never on the product path
+    from tests import synth  # noqa: F401  (same SplitMix64 stream as the device fill)
+    n = 1 << log_n
+    w = pow(7, (P - 1) >> log_n, P)
+    x = synth.field_elements(SEED + 1, n)
+    t0 = time.perf_counter()
+    oracle.fft_fwd(x, w)
+    t_ntt = time.perf_counter() - t0
+    values, sibs, wit, idx, root, _ = merkle_case
+    s = min(merkle_sample, values.shape[0])
+    t0 = time.perf_counter()
+    oracle.merkle_verify_batch(values[:s], sibs[:s], np.ascontiguousarray(wit[:, :s]), idx[:s], root)
+    t_mk = time.perf_counter() - t0
+    return {
+        "value": 1.0 / t_ntt, "unit": "NTT(2^%d)/s" % log_n, "cores": 1, "kind": "port",
+        "sample": "1 forward 2^%d-point transform (%.2f s) and %d depth-20 branches (%.2f s), oracle/stark_oracle.c, 1 thread"
+                  % (log_n, t_ntt, s, t_mk),
+        "merkle_value": s / t_mk, "merkle_unit": "branch verifications/s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--ntt-batch", type=int, default=32, help="polynomials per step per GPU")
+    ap.add_argument("--merkle-n", type=int, default=1 << 20, help="branches per step per GPU")
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    ctx = sv.Context(local_rank)
+    # all work of this process goes to one non-default torch stream, so that the library's
+    # launches and the timing events are on the same queue
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+
+    # ---- region A: 2^log_n-point forward NTT, batch resident in HBM ----
+    log_n, n, B = args.log_n, 1 << args.log_n, args.ntt_batch
+    root = pow(7, (P - 1) >> log_n, P)
+    x = torch.empty(B * n * 8, dtype=torch.int32, device=device)
+    y = torch.empty_like(x)
+    ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, x.data_ptr(), B * n, SEED + 1 + rank, stream))
+    torch.cuda.synchronize()
+
+    def ntt_step():
+        sv.fft.ntt_batch_dev(x.data_ptr(), y.data_ptr(), log_n, B, root, False, ctx, stream)
+
+    ntt_step()  # builds the twiddle tables (plan) outside the timed region
+    torch.cuda.synchronize()
+    # parity guard inside the bench: inverse(forward(x)) == x on the full batch
+    z = torch.empty_like(x)
+    sv.fft.ntt_batch_dev(y.data_ptr(), z.data_ptr(), log_n, B, root, True, ctx, stream)
+    torch.cuda.synchronize()
+    roundtrip_ok = bool(torch.equal(x, z))
+    del z
+    dt_ntt, dev_ms_ntt = timed_region(ntt_step, args.steps, args.warmup, world, device)
+
+    # ---- region B: depth-`depth` Merkle branch verification ----
+    case = build_merkle_case(args.merkle_n, args.depth, SEED + 4 + rank)
+    values, sibs, wit, idx, mroot, expect = case
+    d = {k: torch.from_numpy(v).to(device) for k, v in
+         dict(values=values, sibs=sibs, wit=wit, idx=idx.view(np.int32), root=mroot).items()}
+    acc = torch.zeros(args.merkle_n, dtype=torch.uint8, device=device)
+    w_levels = args.depth - 1
+
+    def merkle_step():
+        ctx.check(ctx.lib.stark_merkle_verify_batch_dev(
+            ctx.handle, d["values"].data_ptr(), d["sibs"].data_ptr(), 32, d["wit"].data_ptr(), w_levels,
+            d["idx"].data_ptr(), d["root"].data_ptr(), None, args.merkle_n, acc.data_ptr(), None, stream))
+
+    merkle_step()
+    torch.cuda.synchronize()
+    accept_ok = bool(np.array_equal(acc.cpu().numpy(), expect))
+    dt_mk, dev_ms_mk = timed_region(merkle_step, args.steps, args.warmup, world, device)
+
+    ok = torch.tensor([int(roundtrip_ok and accept_ok)], device=device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        K = args.steps
+        ntt_per_s = world * B * K / dt_ntt
+        mk_per_s = world * args.merkle_n * K / dt_mk
+        # dominant kernel: the tile-transform pass kernel; a step is `launches` launches of it
+        chunk = max(1, min(B, (512 << 20) // (n * 32)))
+        passes = 1 if log_n <= 12 else 2
+        launches = passes * ((B + chunk - 1) // chunk)
+        launch_s = dev_ms_ntt * 1e-3 / launches
+        ops_per_launch = (n // 2) * log_n * OPS_PER_BUTTERFLY * B / launches
+        bytes_per_launch = 2 * 32 * n * B * passes / launches
+        ntt_tops = ops_per_launch / launch_s * 1e-12
+        mk_ops = args.merkle_n * args.depth * OPS_PER_COMPRESSION
+        mk_bytes = args.merkle_n * (32 + 32 + 32 * w_levels + 4 + 1)
+        out = {
+            "metric": "256-bit NTTs/sec at 2^20 points",
+            "value": ntt_per_s,
+            "unit": "NTT/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": dt_ntt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (256-bit integers mod 2^256-351*2^32+1)",
+            "data": "synthetic (SplitMix64 field elements; hashlib-built BLAKE2s tree)",
+            "config": {"workload": "forward NTT, 2^%d points x %d polynomials per GPU per step, HBM-resident" % (log_n, B),
+                       "log_n": log_n, "ntt_batch_per_gpu": B, "parallelism": "batch sharded, no collective"},
+            "parity": {"ntt_inverse_of_forward_equals_input": roundtrip_ok, "merkle_accept_vector_as_constructed": accept_ok,
+                       "all_ranks": bool(ok.item())},
+            "roofline": {
+                "bound": "valu", "kernel": "ntt29_pass_kernel<%d>" % (log_n if passes == 1 else (log_n + 1) // 2),
+                "achieved": ntt_tops, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (32-bit integer lane-ops)",
+                "frac": ntt_tops / PEAK_VALU_TOPS, "launch_us": launch_s * 1e6, "launches_per_step": launches,
+                "hbm_achieved_GBps": bytes_per_launch / launch_s * 1e-9, "hbm_frac": bytes_per_launch / launch_s * 1e-9 / PEAK_HBM_GBPS,
+                "traffic": None,
+            },
+            "merkle": {
+                "metric": "Merkle branch verifications/sec (depth %d)" % args.depth, "value": mk_per_s, "unit": "branches/s",
+                "ms_per_step": dt_mk / K * 1e3, "branches_per_gpu_per_step": args.merkle_n,
+                "roofline": {"bound": "valu", "kernel": "merkle_verify_kernel<true>",
+                             "achieved": mk_ops / (dev_ms_mk * 1e-3) * 1e-12, "peak": PEAK_VALU_TOPS,
+                             "unit": "Tops/s (32-bit integer lane-ops)",
+                             "frac": mk_ops / (dev_ms_mk * 1e-3) * 1e-12 / PEAK_VALU_TOPS,
+                             "launch_us": dev_ms_mk * 1e3,
+                             "hbm_achieved_GBps": mk_bytes / (dev_ms_mk * 1e-3) * 1e-9,
+                             "hbm_frac": mk_bytes / (dev_ms_mk * 1e-3) * 1e-9 / PEAK_HBM_GBPS, "traffic": None},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(log_n, 50000, case)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if not bool(ok.item()):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

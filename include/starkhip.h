@@ -137,7 +137,8 @@ int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const vo
  * ------------------------------------------------------------------------------------- */
 
 /* Element-wise field arithmetic on host arrays of n*8 limbs: op 0 = a+b, 1 = a-b, 2 = a*b,
- * 3 = canonical form of a (b ignored, may be NULL). Exercises the device arithmetic alone. */
+ * 3 = canonical form of a (b ignored, may be NULL); 4..7 run the transform kernels' 29-bit-limb
+ * arithmetic: 4 = a*b, 5 = a+b, 6 = a-b, 7 = (2a-2b)*b. Exercises the device arithmetic alone. */
 int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n);
 
 /* Fill a device buffer with n canonical field elements drawn from SplitMix64(seed): element i

@@ -32,6 +32,7 @@ struct NttPlan {
     std::vector<PassPlan> passes;
     std::vector<void*> tables;
     bool tiny = false;  // n <= 2
+    bool limb29 = true;  // passes run on the 29-bit-limb kernels (intermediates are 48 bytes/element)
     uint32_t scale[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     int has_scale = 0;
 };
@@ -47,7 +48,7 @@ struct stark_ctx {
     size_t scratch_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
-    size_t chunk_bytes = (size_t)128 << 20;
+    size_t chunk_bytes = (size_t)512 << 20;  // input bytes transformed per group of pass launches
 };
 
 namespace {
@@ -114,18 +115,18 @@ std::vector<int> choose_split(unsigned log_n) {
 }
 
 // Tiles per workgroup (log2): as many as fit the thread and LDS budget and the extent.
-int choose_log_c(int log_t, unsigned log_extent, int target_threads) {
+int choose_log_c(int log_t, unsigned log_extent, int target_threads, bool limb29) {
     int log_q = log_t - 2;
     int log_c = 0;
     int lim = env_int("STARKHIP_LDS_LIMIT", 80 * 1024);
-    while (log_c + 1 <= (int)log_extent && (1 << (log_q + log_c + 1)) <= target_threads &&
-           (int)ntt_pass_lds_bytes(log_t, log_c + 1) <= lim)
+    auto lds = [&](int lc) { return (int)(limb29 ? ntt29_pass_lds_bytes(log_t, lc) : ntt_pass_lds_bytes(log_t, lc)); };
+    while (log_c + 1 <= (int)log_extent && (1 << (log_q + log_c + 1)) <= target_threads && lds(log_c + 1) <= lim)
         log_c++;
     return log_c;
 }
 
 int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, uint64_t row_len, const U256& scale,
-               uint32_t** out) {
+               uint32_t** out, bool unpack = false) {
     uint32_t pw[64 * 8];
     U256 b = base;
     for (int k = 0; k < 64; k++) {
@@ -148,6 +149,17 @@ int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, ui
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_pw);
     if (e != hipSuccess) return fail(ctx, STARK_ERR_HIP, "twiddle table build: %s", hipGetErrorString(e));
+    if (unpack) {  // 12 dwords per entry for the 29-bit-limb kernels
+        void* d_un = nullptr;
+        e = hipMalloc(&d_un, count * 48);
+        if (e != hipSuccess) return fail(ctx, STARK_ERR_NOMEM, "twiddle table of %zu bytes: %s", count * 48, hipGetErrorString(e));
+        e = launch_unpack_table((const uint32_t*)d_tab, (uint32_t*)d_un, count, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tab);
+        plan->tables.back() = d_un;
+        if (e != hipSuccess) return fail(ctx, STARK_ERR_HIP, "twiddle table unpack: %s", hipGetErrorString(e));
+        d_tab = d_un;
+    }
     *out = (uint32_t*)d_tab;
     return STARK_OK;
 }
@@ -179,13 +191,15 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
         return STARK_OK;
     }
 
+    const bool l29 = env_int("STARKHIP_ARITH", 29) != 32;
+    plan->limb29 = l29;
     std::vector<int> split = choose_split(log_n);
     const int target_threads = env_int("STARKHIP_THREADS", 512);
     const int forced_log_c = env_int("STARKHIP_LOGC", -1);
     auto pick_c = [&](int log_t, unsigned log_extent) {
-        int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads);
+        int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads, l29);
         if (forced_log_c >= 0 && forced_log_c <= (int)log_extent && (1 << (log_t - 2 + forced_log_c)) <= 1024 &&
-            ntt_pass_lds_bytes(log_t, forced_log_c) <= 160 * 1024)
+            (l29 ? ntt29_pass_lds_bytes(log_t, forced_log_c) : ntt_pass_lds_bytes(log_t, forced_log_c)) <= 160 * 1024)
             lc = forced_log_c;
         return lc;
     };
@@ -207,7 +221,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
         a.has_scale = plan->has_scale;
         memcpy(a.scale, plan->scale, sizeof a.scale);
         uint32_t* W;
-        if ((rc = make_table(ctx, plan.get(), w, n, 0, one, &W)) != STARK_OK) {
+        if ((rc = make_table(ctx, plan.get(), w, n, 0, one, &W, l29)) != STARK_OK) {
             free_plan(plan.get());
             return rc;
         }
@@ -220,7 +234,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
         const uint64_t n1 = (uint64_t)1 << l1, m = (uint64_t)1 << lm;
         uint32_t *W1, *TW1;
         U256 w1 = hostfe::pow_u64(w, m);  // order n1
-        if ((rc = make_table(ctx, plan.get(), w1, n1, 0, one, &W1)) != STARK_OK ||
+        if ((rc = make_table(ctx, plan.get(), w1, n1, 0, one, &W1, l29)) != STARK_OK ||
             (rc = make_table(ctx, plan.get(), w, n, m, scale, &TW1)) != STARK_OK) {
             free_plan(plan.get());
             return rc;
@@ -250,7 +264,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             const int l2 = split[1];
             uint32_t* W2;
             U256 w2 = hostfe::pow_u64(w, n1);  // order m
-            if ((rc = make_table(ctx, plan.get(), w2, m, 0, one, &W2)) != STARK_OK) {
+            if ((rc = make_table(ctx, plan.get(), w2, m, 0, one, &W2, l29)) != STARK_OK) {
                 free_plan(plan.get());
                 return rc;
             }
@@ -282,8 +296,8 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             U256 wm = hostfe::pow_u64(w, n1);      // order m
             U256 w2 = hostfe::pow_u64(wm, n3);     // order n2
             U256 w3 = hostfe::pow_u64(wm, n2);     // order n3
-            if ((rc = make_table(ctx, plan.get(), w2, n2, 0, one, &W2)) != STARK_OK ||
-                (rc = make_table(ctx, plan.get(), w3, n3, 0, one, &W3)) != STARK_OK ||
+            if ((rc = make_table(ctx, plan.get(), w2, n2, 0, one, &W2, l29)) != STARK_OK ||
+                (rc = make_table(ctx, plan.get(), w3, n3, 0, one, &W3, l29)) != STARK_OK ||
                 (rc = make_table(ctx, plan.get(), wm, m, n3, one, &TW2)) != STARK_OK) {
                 free_plan(plan.get());
                 return rc;
@@ -379,16 +393,20 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.in = d_in + 8 * n * done;
             a.out = d_out + 8 * n * done;
             a.c_limit = cnt;
-            HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
+            if (plan->limb29)
+                HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
+            else
+                HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
         }
         return STARK_OK;
     }
     // multi-pass: first pass into scratch, middle pass in place there, last pass to d_out
+    const size_t mid_bytes = plan->limb29 ? 48 : 32;  // bytes per element of the intermediate
     size_t chunk = ctx->chunk_bytes / (n * 32);
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     if (chunk > 65535) chunk = 65535;
-    int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, chunk * n * 32);
+    int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, chunk * n * mid_bytes);
     if (rc != STARK_OK) return rc;
     uint32_t* tmp = (uint32_t*)ctx->scratch;
     for (size_t done = 0; done < batch; done += chunk) {
@@ -398,7 +416,16 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             NttPassArgs a = p.args;
             a.in = k == 0 ? d_in + 8 * n * done : tmp;
             a.out = k + 1 == plan->passes.size() ? d_out + 8 * n * done : tmp;
-            HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
+            if (plan->limb29) {
+                a.ablate = (uint32_t)env_int("STARKHIP_ABLATE", 0);
+                a.stagger_cycles = (uint32_t)env_int("STARKHIP_STAGGER", 0);
+                if (const char* sp = getenv("STARKHIP_STAMPS_PTR")) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
+                a.in_raw = k > 0;
+                a.out_raw = k + 1 < plan->passes.size();
+                HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
+            } else {
+                HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
+            }
         }
     }
     return STARK_OK;
@@ -577,7 +604,7 @@ int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8
 
 int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) {
     if (!ctx) return STARK_ERR_INVALID;
-    if (op < 0 || op > 3) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);
+    if (op < 0 || op > 7) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);
     if (n == 0) return STARK_OK;
     if (!a || !r || (op != 3 && !b)) return fail(ctx, STARK_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t subb(uint32_t a, uint32_t b, uint32_t& borro
     return r;
 }
 
+// Lane-wise select through a 0 / 0xFFFFFFFF mask: one v_bitop3_b32. (v_cndmask_b32 reading VCC
+// issues several times slower than this on gfx950 when used back to back.)
+__device__ __forceinline__ uint32_t sel32(uint32_t mask, uint32_t if_set, uint32_t if_clear) {
+    return (if_set & mask) | (if_clear & ~mask);
+}
+
 __device__ __forceinline__ Fe fe_zero() {
     Fe r;
 #pragma unroll
@@ -63,8 +69,9 @@ __device__ __forceinline__ Fe fe_canon(const Fe& a) {
 #pragma unroll
     for (int i = 2; i < 8; i++) u.l[i] = addc(a.l[i], 0u, c);
     Fe r;
+    const uint32_t mask = 0u - c;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = c ? u.l[i] : a.l[i];
+    for (int i = 0; i < 8; i++) r.l[i] = sel32(mask, u.l[i], a.l[i]);
     return r;
 }
 
@@ -78,10 +85,10 @@ __device__ __forceinline__ Fe fe_add(const Fe& a, const Fe& b) {
     u.l[1] = addc(s.l[1], FE_C1, c2);
 #pragma unroll
     for (int i = 2; i < 8; i++) u.l[i] = addc(s.l[i], 0u, c2);
-    uint32_t take = c1 | c2;  // a+b >= p  <=>  a+b+(2^256-p) >= 2^256
+    const uint32_t mask = 0u - (c1 | c2);  // a+b >= p  <=>  a+b+(2^256-p) >= 2^256
     Fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = take ? u.l[i] : s.l[i];
+    for (int i = 0; i < 8; i++) r.l[i] = sel32(mask, u.l[i], s.l[i]);
     return r;
 }
 

@@ -1,0 +1,296 @@
+// Carry-free ("unsaturated") arithmetic mod p = 2^256 - 351*2^32 + 1 for gfx950.
+//
+// A value is held as nine limbs of 29 bits, X = sum l[i] * 2^(29 i). Limbs live in 32-bit
+// registers, so up to three spare bits per limb absorb additions without carry chains:
+//   * add / sub are nine independent v_add_u32 / v_sub_u32 (the 2-cycle VALU class) instead
+//     of two 8-limb v_addc_co_u32 chains (4-cycle class) plus selects;
+//   * in the product, a column of nine 61-bit partial products fits a 64-bit accumulator, so
+//     v_mad_u64_u32 accumulates a whole column with no carry-out handling; the column's limb
+//     is the low 29 bits and the rest is the next column's starting value.
+// On this chip v_mad_u64_u32 and v_addc_co_u32 issue at the same rate, so dropping the carry
+// instruction that a saturated 8x32-bit product needs after every multiply-add removes close
+// to half of the multiplier's issue slots.
+//
+// Forms
+//   "lazy"  : limbs < 3 * 2^30, any value below 2^261 that is congruent to the element.
+//   "tight" : limbs 0..7 < 2^29, limb 8 <= 2^24, i.e. value < 2^256 + 2^232. f29_mul returns
+//             tight values; table entries (twiddles) are canonical, which is tight.
+// Results leave this representation through f29_to_fe, which returns the canonical residue, so
+// everything observable is bit-identical to exact integer arithmetic mod p (what the
+// reference's BigInt `%` and utils::negative_to_positive produce, reference src/fft.rs:28,53-57,84).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field.cuh"
+
+namespace starkhip {
+
+struct F29 {
+    uint32_t l[9];
+};
+
+#define F29_MASK 0x1FFFFFFFu
+// 2^261 == F29_FOLD1 * 2^29 + F29_FOLD0 (mod p)   [= 351*2^37 - 32]
+#define F29_FOLD0 0x1FFFFFE0u /* 2^29 - 32 */
+#define F29_FOLD1 89855u      /* 351*2^8 - 1 */
+// 2^256 == F29_C1 * 2^29 + F29_C0 (mod p)         [= 351*2^32 - 1]
+#define F29_C0 0x1FFFFFFFu /* 2^29 - 1 */
+#define F29_C1 2807u
+
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+
+// 8 x 32-bit canonical (or any 256-bit) value -> nine 29-bit limbs
+__device__ __forceinline__ F29 f29_from_fe(const Fe& x) {
+    const uint32_t* w = x.l;
+    F29 r;
+    r.l[0] = w[0] & F29_MASK;
+    r.l[1] = __builtin_amdgcn_alignbit(w[1], w[0], 29) & F29_MASK;
+    r.l[2] = __builtin_amdgcn_alignbit(w[2], w[1], 26) & F29_MASK;
+    r.l[3] = __builtin_amdgcn_alignbit(w[3], w[2], 23) & F29_MASK;
+    r.l[4] = __builtin_amdgcn_alignbit(w[4], w[3], 20) & F29_MASK;
+    r.l[5] = __builtin_amdgcn_alignbit(w[5], w[4], 17) & F29_MASK;
+    r.l[6] = __builtin_amdgcn_alignbit(w[6], w[5], 14) & F29_MASK;
+    r.l[7] = __builtin_amdgcn_alignbit(w[7], w[6], 11) & F29_MASK;
+    r.l[8] = w[7] >> 8;
+    return r;
+}
+
+// One sequential carry pass: limbs 0..7 end below 2^29, limb 8 takes what is left.
+__device__ __forceinline__ F29 f29_carry(const F29& a) {
+    F29 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = a.l[i] + c;
+        r.l[i] = v & F29_MASK;
+        c = v >> 29;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+
+__device__ __forceinline__ F29 f29_add(const F29& a, const F29& b) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+// a - b + 2p for tight b: 2p written with limbs that dominate a tight value's limbs
+// {2^29+2, 2^30-5617, 2^30-2 (x6), 2^25-2}, so no limb goes negative.
+__device__ __forceinline__ F29 f29_sub(const F29& a, const F29& b) {
+    F29 r;
+    r.l[0] = a.l[0] + (0x20000002u - b.l[0]);
+    r.l[1] = a.l[1] + (0x3FFFEA0Fu - b.l[1]);
+#pragma unroll
+    for (int i = 2; i < 8; i++) r.l[i] = a.l[i] + (0x3FFFFFFEu - b.l[i]);
+    r.l[8] = a.l[8] + (0x01FFFFFEu - b.l[8]);
+    return r;
+}
+
+// a - b + 4p for b a sum of two tight values (limbs < 2^30, limb 8 <= 2^25):
+// 4p = {2^30+4, 2^31-11233, 2^31-3 ... } rewritten so every limb dominates:
+// {2^30+4, 2^31-11234, 2^31-4 (x6), 2^26-4}
+__device__ __forceinline__ F29 f29_sub2(const F29& a, const F29& b) {
+    F29 r;
+    r.l[0] = a.l[0] + (0x40000004u - b.l[0]);
+    r.l[1] = a.l[1] + (0x7FFFD41Eu - b.l[1]);
+#pragma unroll
+    for (int i = 2; i < 8; i++) r.l[i] = a.l[i] + (0x7FFFFFFCu - b.l[i]);
+    r.l[8] = a.l[8] + (0x03FFFFFCu - b.l[8]);
+    return r;
+}
+
+// acc += sum of N products, as one strictly serial v_mad_u64_u32 chain (the compiler would
+// otherwise start a second accumulator per column and pay a 64-bit add to merge it).
+#define F29_M(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\t"
+#define F29_P(x, y) "v"(x), "v"(y)
+#define F29_K(x, c) "v"(x), "s"(c)
+
+// a * b mod p (not fully reduced): a lazy (limbs < 3*2^30), b tight. Returns a tight value.
+__device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
+    const uint32_t* a = x.l;
+    const uint32_t* b = y.l;
+    const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1;
+    // columns 9..16 first: their 29-bit limbs th[0..8] sit at 2^261 * 2^(29 k)
+    uint32_t th[9];
+    uint64_t acc = 0;
+#define F29_NEXT(dst)                       \
+    dst = (uint32_t)acc & F29_MASK;         \
+    acc >>= 29;
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+        : "+v"(acc)
+        : F29_P(a[1], b[8]), F29_P(a[2], b[7]), F29_P(a[3], b[6]), F29_P(a[4], b[5]), F29_P(a[5], b[4]),
+          F29_P(a[6], b[3]), F29_P(a[7], b[2]), F29_P(a[8], b[1])
+        : "vcc");
+    F29_NEXT(th[0])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14)
+        : "+v"(acc)
+        : F29_P(a[2], b[8]), F29_P(a[3], b[7]), F29_P(a[4], b[6]), F29_P(a[5], b[5]), F29_P(a[6], b[4]),
+          F29_P(a[7], b[3]), F29_P(a[8], b[2])
+        : "vcc");
+    F29_NEXT(th[1])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
+        : "+v"(acc)
+        : F29_P(a[3], b[8]), F29_P(a[4], b[7]), F29_P(a[5], b[6]), F29_P(a[6], b[5]), F29_P(a[7], b[4]),
+          F29_P(a[8], b[3])
+        : "vcc");
+    F29_NEXT(th[2])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
+        : "+v"(acc)
+        : F29_P(a[4], b[8]), F29_P(a[5], b[7]), F29_P(a[6], b[6]), F29_P(a[7], b[5]), F29_P(a[8], b[4])
+        : "vcc");
+    F29_NEXT(th[3])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
+        : "+v"(acc)
+        : F29_P(a[5], b[8]), F29_P(a[6], b[7]), F29_P(a[7], b[6]), F29_P(a[8], b[5])
+        : "vcc");
+    F29_NEXT(th[4])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : F29_P(a[6], b[8]), F29_P(a[7], b[7]), F29_P(a[8], b[6]) : "vcc");
+    F29_NEXT(th[5])
+    asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_P(a[7], b[8]), F29_P(a[8], b[7]) : "vcc");
+    F29_NEXT(th[6])
+    asm(F29_M(1, 2) : "+v"(acc) : F29_P(a[8], b[8]) : "vcc");
+    F29_NEXT(th[7])
+    th[8] = (uint32_t)acc;  // below 2^27
+    // columns 0..8 with the high limbs folded in: 2^261 * t == (FOLD1 * 2^29 + FOLD0) * t
+    uint32_t r[9];
+    acc = 0;
+    asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_P(a[0], b[0]), F29_K(th[0], f0) : "vcc");
+    F29_NEXT(r[0])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
+        : "+v"(acc)
+        : F29_P(a[0], b[1]), F29_P(a[1], b[0]), F29_K(th[1], f0), F29_K(th[0], f1)
+        : "vcc");
+    F29_NEXT(r[1])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
+        : "+v"(acc)
+        : F29_P(a[0], b[2]), F29_P(a[1], b[1]), F29_P(a[2], b[0]), F29_K(th[2], f0), F29_K(th[1], f1)
+        : "vcc");
+    F29_NEXT(r[2])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
+        : "+v"(acc)
+        : F29_P(a[0], b[3]), F29_P(a[1], b[2]), F29_P(a[2], b[1]), F29_P(a[3], b[0]), F29_K(th[3], f0),
+          F29_K(th[2], f1)
+        : "vcc");
+    F29_NEXT(r[3])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14)
+        : "+v"(acc)
+        : F29_P(a[0], b[4]), F29_P(a[1], b[3]), F29_P(a[2], b[2]), F29_P(a[3], b[1]), F29_P(a[4], b[0]),
+          F29_K(th[4], f0), F29_K(th[3], f1)
+        : "vcc");
+    F29_NEXT(r[4])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+        : "+v"(acc)
+        : F29_P(a[0], b[5]), F29_P(a[1], b[4]), F29_P(a[2], b[3]), F29_P(a[3], b[2]), F29_P(a[4], b[1]),
+          F29_P(a[5], b[0]), F29_K(th[5], f0), F29_K(th[4], f1)
+        : "vcc");
+    F29_NEXT(r[5])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+            F29_M(17, 18)
+        : "+v"(acc)
+        : F29_P(a[0], b[6]), F29_P(a[1], b[5]), F29_P(a[2], b[4]), F29_P(a[3], b[3]), F29_P(a[4], b[2]),
+          F29_P(a[5], b[1]), F29_P(a[6], b[0]), F29_K(th[6], f0), F29_K(th[5], f1)
+        : "vcc");
+    F29_NEXT(r[6])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+            F29_M(17, 18) F29_M(19, 20)
+        : "+v"(acc)
+        : F29_P(a[0], b[7]), F29_P(a[1], b[6]), F29_P(a[2], b[5]), F29_P(a[3], b[4]), F29_P(a[4], b[3]),
+          F29_P(a[5], b[2]), F29_P(a[6], b[1]), F29_P(a[7], b[0]), F29_K(th[7], f0), F29_K(th[6], f1)
+        : "vcc");
+    F29_NEXT(r[7])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+            F29_M(17, 18) F29_M(19, 20) F29_M(21, 22)
+        : "+v"(acc)
+        : F29_P(a[0], b[8]), F29_P(a[1], b[7]), F29_P(a[2], b[6]), F29_P(a[3], b[5]), F29_P(a[4], b[4]),
+          F29_P(a[5], b[3]), F29_P(a[6], b[2]), F29_P(a[7], b[1]), F29_P(a[8], b[0]), F29_K(th[8], f0),
+          F29_K(th[7], f1)
+        : "vcc");
+    F29_NEXT(r[8])
+#undef F29_NEXT
+    acc = mad64(th[8], F29_FOLD1, acc);  // what remains at 2^261: below 2^45
+    // second fold at 2^256: top = everything above bit 256 = (acc << 5) | (r[8] >> 24)
+    uint64_t top = (acc << 5) | (uint64_t)(r[8] >> 24);
+    r[8] &= 0x00FFFFFFu;
+    uint32_t u0 = (uint32_t)top & F29_MASK, u1 = (uint32_t)(top >> 29);  // u1 < 2^21
+    F29 o;
+    acc = mad64(u0, F29_C0, (uint64_t)r[0]);
+    o.l[0] = (uint32_t)acc & F29_MASK;
+    acc >>= 29;
+    acc = mad64(u0, F29_C1, acc + r[1]);
+    acc = mad64(u1, F29_C0, acc);
+    o.l[1] = (uint32_t)acc & F29_MASK;
+    acc >>= 29;
+    acc = mad64(u1, F29_C1, acc + r[2]);
+    o.l[2] = (uint32_t)acc & F29_MASK;
+    uint32_t c = (uint32_t)(acc >> 29);  // small: u1*C1 < 2^33, shifted down by 29
+#pragma unroll
+    for (int i = 3; i < 8; i++) {
+        uint32_t v = r[i] + c;
+        o.l[i] = v & F29_MASK;
+        c = v >> 29;
+    }
+    o.l[8] = r[8] + c;  // <= 2^24
+    return o;
+}
+
+// Any lazy value -> canonical residue as 8 x 32-bit limbs.
+__device__ __forceinline__ Fe f29_to_fe(const F29& x) {
+    F29 v = f29_carry(x);  // limbs 0..7 < 2^29, limb 8 < 2^32
+    // fold what lies above bit 256: e * 2^256 == e * (2808 * 2^29 - 1)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        uint32_t e = v.l[8] >> 24;
+        v.l[8] &= 0x00FFFFFFu;
+        int32_t s0 = (int32_t)v.l[0] - (int32_t)e;  // may be negative: signed carry below
+        v.l[0] = (uint32_t)s0 & F29_MASK;
+        int32_t c = s0 >> 29;
+        uint32_t s1 = v.l[1] + 2808u * e + (uint32_t)c;  // non-negative: e > 0 whenever c < 0
+        v.l[1] = s1 & F29_MASK;
+        uint32_t cc = s1 >> 29;
+#pragma unroll
+        for (int i = 2; i < 8; i++) {
+            uint32_t t = v.l[i] + cc;
+            v.l[i] = t & F29_MASK;
+            cc = t >> 29;
+        }
+        v.l[8] += cc;
+    }
+    // now value < 2^256 (second pass folds at most a single 2^256, leaving a tiny remainder).
+    // canonical: subtract p when value >= p, i.e. when value + (2^256 - p) reaches 2^256
+    F29 u;
+    {
+        uint32_t t = v.l[0] + F29_C0;
+        u.l[0] = t & F29_MASK;
+        uint32_t cc = t >> 29;
+        t = v.l[1] + F29_C1 + cc;
+        u.l[1] = t & F29_MASK;
+        cc = t >> 29;
+#pragma unroll
+        for (int i = 2; i < 8; i++) {
+            t = v.l[i] + cc;
+            u.l[i] = t & F29_MASK;
+            cc = t >> 29;
+        }
+        u.l[8] = v.l[8] + cc;
+    }
+    const uint32_t take = 0u - (u.l[8] >> 24);  // all ones: value >= p, use u minus 2^256
+    u.l[8] &= 0x00FFFFFFu;
+    uint32_t l[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) l[i] = sel32(take, u.l[i], v.l[i]);
+    Fe r;
+    r.l[0] = l[0] | (l[1] << 29);
+    r.l[1] = (l[1] >> 3) | (l[2] << 26);
+    r.l[2] = (l[2] >> 6) | (l[3] << 23);
+    r.l[3] = (l[3] >> 9) | (l[4] << 20);
+    r.l[4] = (l[4] >> 12) | (l[5] << 17);
+    r.l[5] = (l[5] >> 15) | (l[6] << 14);
+    r.l[6] = (l[6] >> 18) | (l[7] << 11);
+    r.l[7] = (l[7] >> 21) | (l[8] << 8);
+    return r;
+}
+
+}  // namespace starkhip

@@ -34,12 +34,22 @@ struct NttPassArgs {
     uint32_t log_c;
     uint32_t load_cfast, store_cfast;  // lane order: tile index fastest (1) or element index fastest (0)
     uint32_t canon_in;   // inputs may be any 256-bit value: reduce on load (first pass only)
+    // persistent launch (29-bit-limb kernels): a workgroup loops over work items w = blockIdx.x + k*gridDim.x,
+    // item -> (tile tau, polynomial); xcd_map groups the items that share an inter-pass twiddle tile on one XCD
+    uint32_t tiles, polys, xcd_map, stagger_cycles;
+    unsigned long long* stamps;  // diagnostic builds only: per-workgroup phase timestamps, or null
+    uint32_t ablate;  // diagnostic timing builds only: 1 no twiddle loads, 2 no LDS exchange, 4 no global loads, 8 no stores
+    uint32_t in_raw, out_raw;  // 29-bit-limb kernels: element is 12 unpacked dwords instead of 8 packed
     uint32_t has_scale;
     uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)
 };
 
 size_t ntt_pass_lds_bytes(int log_t, int log_c);
 hipError_t launch_ntt_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
+// the same pass on 29-bit-limb arithmetic (ntt29.hip); W entries are 12 unpacked dwords
+size_t ntt29_pass_lds_bytes(int log_t, int log_c);
+hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
+hipError_t launch_unpack_table(const uint32_t* in, uint32_t* out, size_t count, hipStream_t stream);
 // n = 1 or 2 (no radix-4 round exists): out = transform(in), one lane per polynomial
 hipError_t launch_ntt_tiny(const uint32_t* in, uint32_t* out, int log_n, size_t batch, const uint32_t scale[8],
                            int has_scale, hipStream_t stream);

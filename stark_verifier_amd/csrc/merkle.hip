@@ -40,6 +40,11 @@ __device__ __forceinline__ uint32_t leaf_word(const uint8_t* first, const uint8_
     return r;
 }
 
+// Lane-wise select through a 0 / 0xFFFFFFFF mask (one v_bitop3_b32).
+__device__ __forceinline__ uint32_t pick(uint32_t mask, uint32_t if_set, uint32_t if_clear) {
+    return (if_set & mask) | (if_clear & ~mask);
+}
+
 template <bool VS32>
 __global__ void __launch_bounds__(256)
 merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restrict__ siblings, uint32_t value_size,
@@ -67,12 +72,14 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
         const uint4* v = reinterpret_cast<const uint4*>(values) + 2 * i;
         const uint4* s = reinterpret_cast<const uint4*>(siblings) + 2 * i;
         uint4 v0 = v[0], v1 = v[1], s0 = s[0], s1 = s[1];
-        bool odd = idx & 1u;
-        uint4 f0 = odd ? s0 : v0, f1 = odd ? s1 : v1, g0 = odd ? v0 : s0, g1 = odd ? v1 : s1;
-        m[0] = f0.x; m[1] = f0.y; m[2] = f0.z; m[3] = f0.w;
-        m[4] = f1.x; m[5] = f1.y; m[6] = f1.z; m[7] = f1.w;
-        m[8] = g0.x; m[9] = g0.y; m[10] = g0.z; m[11] = g0.w;
-        m[12] = g1.x; m[13] = g1.y; m[14] = g1.z; m[15] = g1.w;
+        const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t odd = 0u - (idx & 1u);  // all ones: sibling first
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            m[j] = pick(odd, sw[j], vw[j]);
+            m[8 + j] = pick(odd, vw[j], sw[j]);
+        }
         b2s_hash64(h, m);
     } else {
         const uint8_t* v = values + (size_t)value_size * i;
@@ -100,11 +107,13 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
             w_lo = np[0];
             w_hi = np[1];
         }
-        bool odd = pos & 1u;
-        m[0] = odd ? c_lo.x : h[0]; m[1] = odd ? c_lo.y : h[1]; m[2] = odd ? c_lo.z : h[2]; m[3] = odd ? c_lo.w : h[3];
-        m[4] = odd ? c_hi.x : h[4]; m[5] = odd ? c_hi.y : h[5]; m[6] = odd ? c_hi.z : h[6]; m[7] = odd ? c_hi.w : h[7];
-        m[8] = odd ? h[0] : c_lo.x; m[9] = odd ? h[1] : c_lo.y; m[10] = odd ? h[2] : c_lo.z; m[11] = odd ? h[3] : c_lo.w;
-        m[12] = odd ? h[4] : c_hi.x; m[13] = odd ? h[5] : c_hi.y; m[14] = odd ? h[6] : c_hi.z; m[15] = odd ? h[7] : c_hi.w;
+        const uint32_t ww[8] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w, c_hi.x, c_hi.y, c_hi.z, c_hi.w};
+        const uint32_t odd = 0u - (pos & 1u);  // all ones: witness first
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            m[j] = pick(odd, ww[j], h[j]);
+            m[8 + j] = pick(odd, h[j], ww[j]);
+        }
         b2s_hash64(h, m);
         pos >>= 1;
     }

@@ -19,6 +19,7 @@
 // inverse root; its n^-1 factor is folded into the inter-pass twiddle table (or, for
 // single-pass sizes, applied at the final store).
 #include "field.cuh"
+#include "field29.cuh"
 #include "internal.hpp"
 
 namespace starkhip {
@@ -271,7 +272,18 @@ __global__ void field_op_kernel(int op, const uint32_t* __restrict__ a, const ui
     if (op == 0) z = fe_add(x, y);
     else if (op == 1) z = fe_sub(x, y);
     else if (op == 2) z = fe_mul(x, y);
-    else z = x;
+    else if (op == 3) z = x;
+    else {
+        // the 29-bit-limb arithmetic, entered with the raw (possibly non-canonical) a
+        F29 xa = f29_from_fe(fe_load(a + 8 * i)), yb = f29_from_fe(y);
+        if (op == 4) z = f29_to_fe(f29_mul(xa, yb));
+        else if (op == 5) z = f29_to_fe(f29_add(xa, yb));
+        else if (op == 6) z = f29_to_fe(f29_sub(xa, yb));
+        else {  // op 7: (2a - 2b) * b with the multiplier's first operand at its lazy bound
+            F29 t = f29_sub2(f29_add(xa, xa), f29_add(yb, yb));
+            z = f29_to_fe(f29_mul(t, yb));
+        }
+    }
     fe_store(r + 8 * i, z);
 }
 

@@ -85,7 +85,7 @@ def ntt_batch_dev(d_in: int, d_out: int, log_n: int, batch: int, root_of_unity: 
 
 def field_op(op: str, a: np.ndarray, b: np.ndarray | None = None, ctx: _lib.Context | None = None) -> np.ndarray:
     ctx = ctx or _lib.default_context()
-    code = {"add": 0, "sub": 1, "mul": 2, "canon": 3}[op]
+    code = {"add": 0, "sub": 1, "mul": 2, "canon": 3, "mul29": 4, "add29": 5, "sub29": 6, "lazymul29": 7}[op]
     a = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1, 8)
     bb = None if b is None else np.ascontiguousarray(b, dtype=np.uint32).reshape(-1, 8)
     r = np.empty_like(a)

@@ -56,6 +56,28 @@ def test_field_ops_edges_and_random(sv):
     assert got == [x % P for x in a[:m]]
 
 
+def test_field29_ops_edges_and_random(sv):
+    """The carry-free 29-bit-limb arithmetic the transform kernels use, against Python integers."""
+    rng = random.Random(12)
+    xs = EDGE + [rng.getrandbits(256) for _ in range(48)]
+    a = [x for x in xs for _ in xs]
+    b = [y for _ in xs for y in xs]
+    a += [rng.getrandbits(256) for _ in range(60000)]
+    b += [rng.getrandbits(256) for _ in range(60000)]
+    # operands built from all-ones / all-zero 29-bit limbs stress the carry paths
+    lim = [0, (1 << 29) - 1, 1 << 28, 1, (1 << 29) - 2]
+    for _ in range(4000):
+        a.append(sum(rng.choice(lim) << (29 * i) for i in range(9)) % (1 << 256))
+        b.append(sum(rng.choice(lim) << (29 * i) for i in range(9)) % (1 << 256))
+    A, B = oracle.ints_to_limbs(a), oracle.ints_to_limbs(b)
+    for op, f in (("mul29", lambda x, y: x * (y % P) % P), ("add29", lambda x, y: (x + y) % P),
+                  ("sub29", lambda x, y: (x - y) % P), ("lazymul29", lambda x, y: (2 * x - 2 * y) * y % P)):
+        got = oracle.limbs_to_ints(sv.fft.field_op(op, A, B))
+        exp = [f(x, y) for x, y in zip(a, b)]
+        bad = [i for i in range(len(a)) if got[i] != exp[i]]
+        assert not bad, (op, len(bad), hex(a[bad[0]]), hex(b[bad[0]]))
+
+
 # ---- NTT ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("log_n", list(range(0, 15)))
@@ -307,3 +329,16 @@ def test_merkle_1m_depth20_full_size_properties(sv):
     exp_s = oracle.merkle_verify_batch(case["values"][sample], case["siblings"][sample],
                                        np.ascontiguousarray(wit[:, sample]), case["indices"][sample], case["root"])
     assert np.array_equal(acc[sample], exp_s)
+
+
+def test_cpp_host_mirror_binary(sv):
+    """host/stark_host.hpp (the C++ mirror of fft_inv / ProofBranch::verify / MultiProof::verify)
+    driven by host/test_host.cpp: the reference's unit-test vector and its fft_inv call site."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "test_host")
+    if not os.path.exists(exe):
+        pytest.fail("host/test_host is not built (make -C stark_verifier_amd/csrc host)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "host mirror ok" in r.stdout, r.stdout + r.stderr
