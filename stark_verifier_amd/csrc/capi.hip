@@ -417,9 +417,6 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.in = k == 0 ? d_in + 8 * n * done : tmp;
             a.out = k + 1 == plan->passes.size() ? d_out + 8 * n * done : tmp;
             if (plan->limb29) {
-                a.ablate = (uint32_t)env_int("STARKHIP_ABLATE", 0);
-                a.stagger_cycles = (uint32_t)env_int("STARKHIP_STAGGER", 0);
-                if (const char* sp = getenv("STARKHIP_STAMPS_PTR")) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
                 a.in_raw = k > 0;
                 a.out_raw = k + 1 < plan->passes.size();
                 HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));

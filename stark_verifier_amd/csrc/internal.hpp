@@ -34,11 +34,10 @@ struct NttPassArgs {
     uint32_t log_c;
     uint32_t load_cfast, store_cfast;  // lane order: tile index fastest (1) or element index fastest (0)
     uint32_t canon_in;   // inputs may be any 256-bit value: reduce on load (first pass only)
-    // persistent launch (29-bit-limb kernels): a workgroup loops over work items w = blockIdx.x + k*gridDim.x,
-    // item -> (tile tau, polynomial); xcd_map groups the items that share an inter-pass twiddle tile on one XCD
-    uint32_t tiles, polys, xcd_map, stagger_cycles;
-    unsigned long long* stamps;  // diagnostic builds only: per-workgroup phase timestamps, or null
-    uint32_t ablate;  // diagnostic timing builds only: 1 no twiddle loads, 2 no LDS exchange, 4 no global loads, 8 no stores
+    uint32_t tiles, polys;  // 29-bit-limb kernels: grid = tiles * polys work items
+    uint32_t grp_log;       // 0 = plain order, g + 1 = L2-grouped order with 2^g adjacent tiles per group
+    uint32_t abl;
+    uint32_t store_local;  // 29-bit-limb kernels: last round keeps the wave-local lane order (no extra exchange)
     uint32_t in_raw, out_raw;  // 29-bit-limb kernels: element is 12 unpacked dwords instead of 8 packed
     uint32_t has_scale;
     uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)

@@ -221,6 +221,26 @@ __global__ void __launch_bounds__(256) k_copy(const uint4* __restrict__ in, uint
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// class-transition test: 16 v_xor_b32 (2-cycle class) + 16 v_alignbit_b32 (4-cycle class) per trip,
+// alternating one by one, in groups of four, or in groups of sixteen; chains are independent.
+#define XR(i) "v_xor_b32 %" #i ", %" #i ", %8\n\t"
+#define AL(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 12\n\t"
+#define MIXKERNEL(NAME, BODY)                                                         \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t s) {          \
+        uint32_t r[8];                                                                \
+        uint32_t x = s ^ threadIdx.x, y = s * 2654435761u + blockIdx.x;               \
+        for (int i = 0; i < 8; i++) r[i] = x * (i + 3) + y;                           \
+        for (int it = 0; it < ITERS; it++) {                                          \
+            asm volatile(BODY : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(x)); \
+        }                                                                             \
+        uint32_t acc = 0;                                                             \
+        for (int i = 0; i < 8; i++) acc ^= r[i];                                      \
+        if (acc == 0x12345) out[0] = acc;                                             \
+    }
+MIXKERNEL(k_mix_alt, XR(0) AL(1) XR(2) AL(3) XR(4) AL(5) XR(6) AL(7) XR(1) AL(0) XR(3) AL(2) XR(5) AL(4) XR(7) AL(6) XR(0) AL(1) XR(2) AL(3) XR(4) AL(5) XR(6) AL(7) XR(1) AL(0) XR(3) AL(2) XR(5) AL(4) XR(7) AL(6))
+MIXKERNEL(k_mix_g4, XR(0) XR(1) XR(2) XR(3) AL(4) AL(5) AL(6) AL(7) XR(4) XR(5) XR(6) XR(7) AL(0) AL(1) AL(2) AL(3) XR(0) XR(1) XR(2) XR(3) AL(4) AL(5) AL(6) AL(7) XR(4) XR(5) XR(6) XR(7) AL(0) AL(1) AL(2) AL(3))
+MIXKERNEL(k_mix_g16, XR(0) XR(1) XR(2) XR(3) XR(4) XR(5) XR(6) XR(7) XR(0) XR(1) XR(2) XR(3) XR(4) XR(5) XR(6) XR(7) AL(0) AL(1) AL(2) AL(3) AL(4) AL(5) AL(6) AL(7) AL(0) AL(1) AL(2) AL(3) AL(4) AL(5) AL(6) AL(7))
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 
 static double time_kernel(kern_t k, int blocks, uint32_t* d_out, int reps) {
@@ -257,7 +277,7 @@ int main(int argc, char** argv) {
         {"v_mul_hi_u32_u24", k_mulhi24, 1}, {"v_mad_u32_u24", k_mad24, 1}, {"v_dot4_u32_u8", k_dot4, 1},
         {"v_dot2_u32_u16", k_dot2, 1}, {"v_fma_f32", k_fma32, 1}, {"v_mad_u64_u32", k_mad64, 1},
         {"v_mad_u64_u32+v_addc_co_u32", k_mad64c, 1}, {"v_lshl_add_u64", k_lshladd64, 1},
-        {"v_fma_f64", k_fma64, 1}, {"v_mul_f64", k_mul64f, 1}, {"v_add_f64", k_add64f, 1}, {"[xor;alignbit dependent pair] x8 chains", k_xoralign, 1}, {"v_xor_b32 one dependent chain", k_xordep, 1}, {"v_alignbit one dependent chain", k_aligndep, 1}, {"[xor;xor dependent pair]", k_xor2, 1}, {"[xor;add dependent pair]", k_xoradd, 1}, {"v_mad_u64_u32 one dependent chain", k_mad64dep, 1}, {"[mad64; and independent pair]", k_madand, 1}, {"[v_cmp;v_cndmask vcc]", k_cmpcnd, 1}, {"[v_cmp;4x v_cndmask vcc]", k_cmpcnd4, 1}, {"[v_cmp_e64;4x v_cndmask_e64 sgpr]", k_cmpcnd4s, 1}, {"[xor;and;xor select]", k_selarith, 1}, {"v_bitop3_b32(select 0xca)", k_bitopsel, 1}, {"v_mov_b32", k_mov, 1}, {"v_and_b32", k_and, 1}, {"v_or_b32", k_or, 1}, {"v_sub_u32", k_sub, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_cndmask_b32_e64(sgpr)", k_cnd_s, 1}, {"v_cmp_lt_u32(vcc)", k_cmp, 1}, {"v_cmp_lt_u32_e64(sgpr)", k_cmp_s, 1}, {"v_add_co_u32_e64(sgpr)", k_addco_s, 1}, {"v_lshl_or_b32", k_lshlor, 1}, {"v_and_or_b32", k_andor, 1}, {"v_or3_b32", k_or3, 1}, {"v_lshl_add_u32", k_lshladd, 1}, {"v_add_lshl_u32", k_addlshl, 1}, {"v_xad_u32", k_xad, 1}, {"v_bfe_u32", k_bfe, 1}, {"v_mul_f32", k_mulf32, 1}, {"v_mad_i32_i24", k_madi24, 1}, {"v_pk_add_u16", k_pkadd16, 1}, {"v_pk_mad_u16", k_pkmad16, 1}, {"v_pk_mul_lo_u16", k_pkmul16, 1}, {"v_mov_b32_sdwa(rot16)", k_sdwarot, 1}, {"v_mad_u16", k_madu16, 1}, {"v_mad_u32_u16", k_madu32u16, 1}, {"v_min_u32", k_minu, 1}, {"v_pk_fma_f32", k_pkfma32, 1}, {"v_cvt_f64_u32", k_cvtf64u32, 1}, {"v_lshlrev_b64", k_lshl64, 1}, {"v_lshrrev_b64", k_lshr64, 1}};
+        {"v_fma_f64", k_fma64, 1}, {"v_mul_f64", k_mul64f, 1}, {"v_add_f64", k_add64f, 1}, {"mix 16xor+16alignbit alternating (per 32)", k_mix_alt, 1}, {"mix groups of 4 (per 32)", k_mix_g4, 1}, {"mix groups of 16 (per 32)", k_mix_g16, 1}, {"[xor;alignbit dependent pair] x8 chains", k_xoralign, 1}, {"v_xor_b32 one dependent chain", k_xordep, 1}, {"v_alignbit one dependent chain", k_aligndep, 1}, {"[xor;xor dependent pair]", k_xor2, 1}, {"[xor;add dependent pair]", k_xoradd, 1}, {"v_mad_u64_u32 one dependent chain", k_mad64dep, 1}, {"[mad64; and independent pair]", k_madand, 1}, {"[v_cmp;v_cndmask vcc]", k_cmpcnd, 1}, {"[v_cmp;4x v_cndmask vcc]", k_cmpcnd4, 1}, {"[v_cmp_e64;4x v_cndmask_e64 sgpr]", k_cmpcnd4s, 1}, {"[xor;and;xor select]", k_selarith, 1}, {"v_bitop3_b32(select 0xca)", k_bitopsel, 1}, {"v_mov_b32", k_mov, 1}, {"v_and_b32", k_and, 1}, {"v_or_b32", k_or, 1}, {"v_sub_u32", k_sub, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_cndmask_b32_e64(sgpr)", k_cnd_s, 1}, {"v_cmp_lt_u32(vcc)", k_cmp, 1}, {"v_cmp_lt_u32_e64(sgpr)", k_cmp_s, 1}, {"v_add_co_u32_e64(sgpr)", k_addco_s, 1}, {"v_lshl_or_b32", k_lshlor, 1}, {"v_and_or_b32", k_andor, 1}, {"v_or3_b32", k_or3, 1}, {"v_lshl_add_u32", k_lshladd, 1}, {"v_add_lshl_u32", k_addlshl, 1}, {"v_xad_u32", k_xad, 1}, {"v_bfe_u32", k_bfe, 1}, {"v_mul_f32", k_mulf32, 1}, {"v_mad_i32_i24", k_madi24, 1}, {"v_pk_add_u16", k_pkadd16, 1}, {"v_pk_mad_u16", k_pkmad16, 1}, {"v_pk_mul_lo_u16", k_pkmul16, 1}, {"v_mov_b32_sdwa(rot16)", k_sdwarot, 1}, {"v_mad_u16", k_madu16, 1}, {"v_mad_u32_u16", k_madu32u16, 1}, {"v_min_u32", k_minu, 1}, {"v_pk_fma_f32", k_pkfma32, 1}, {"v_cvt_f64_u32", k_cvtf64u32, 1}, {"v_lshlrev_b64", k_lshl64, 1}, {"v_lshrrev_b64", k_lshr64, 1}};
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"waves_per_simd\": %d, \"rates_Gops\": {",
            prop.gcnArchName, cus, prop.clockRate / 1000, waves_per_simd);
     bool first = true;

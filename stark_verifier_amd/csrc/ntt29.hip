@@ -18,6 +18,11 @@
 
 namespace starkhip {
 
+// Position swizzle inside a tile row: XOR bits 2..6 into bits 0..4. With it both the unit-stride
+// reads (element j + q*T/4) and the strided Stockham writes (stride 4*Ns) of every round land on
+// 32 distinct banks per 32-lane group; without it the writes are up to 4-way conflicted.
+__device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 2) & 31u); }
+
 __device__ __forceinline__ void lds_put29(uint32_t* lds, uint32_t plane, uint32_t off, const F29& v) {
 #pragma unroll
     for (int l = 0; l < 9; l++) lds[l * plane + off] = v.l[l];
@@ -33,11 +38,11 @@ __device__ __forceinline__ F29 lds_get29(const uint32_t* lds, uint32_t plane, ui
 // unpacked element in global memory: 12 dwords (limbs 0..8, three unused)
 __device__ __forceinline__ F29 f29_load_raw(const uint32_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1], c = q[2];
+    uint4 a = q[0], b = q[1];
     F29 r;
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x;
+    r.l[8] = p[8];  // one dword: the three padding dwords are never fetched into registers
     return r;
 }
 
@@ -48,73 +53,84 @@ __device__ __forceinline__ void f29_store_raw(uint32_t* p, const F29& v) {
     q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
 }
 
+// ---- LDS image of a tile -------------------------------------------------------------------
+// A tile of T = 2^LOGT points is worked on by T/4 lanes (radix-4 per lane) = W = T/256 wavefronts
+// (one when T <= 256). Position p of the tile lives in sub-image (p mod W) at offset p / W, so
+// that from the round with sub-transform length Ns >= W onwards every wavefront reads and
+// writes only its own sub-image: the lane that runs butterfly j of such a round is lane j / W
+// of wavefront j mod W, and the Stockham write index keeps the low log2(W) bits of j in place.
+// Those rounds exchange data through LDS without any workgroup barrier; only the rounds before
+// them (and a last round that switches to a store-friendly lane order) need s_barrier.
+template <int LOGT>
+struct TileGeom {
+    static constexpr int LW = LOGT > 8 ? LOGT - 8 : 0;  // log2(wavefronts per tile)
+    static constexpr uint32_t W = 1u << LW;
+    static constexpr uint32_t B = (1u << LOGT) >> LW;   // sub-image length (<= 256)
+    static constexpr uint32_t SB = B + (LW ? 8u : 0u);  // sub-image stride: +8 keeps cross-wave rounds off one bank
+    static constexpr uint32_t ROW = W * SB;             // dwords of one limb plane of one tile
+};
+
 __host__ __device__ inline uint32_t tile_pad29(uint32_t log_c) {
     if (log_c == 0) return 0;
     return log_c >= 5 ? 1u : (32u >> log_c);
 }
 
 size_t ntt29_pass_lds_bytes(int log_t, int log_c) {
-    size_t tp = ((size_t)1 << log_t) + tile_pad29((uint32_t)log_c);
-    return 36 * tp << log_c;
+    const int lw = log_t > 8 ? log_t - 8 : 0;
+    size_t row = (((size_t)1 << log_t) >> lw) + (lw ? 8 : 0);
+    row = (row << lw) + tile_pad29((uint32_t)log_c);
+    return 36 * row << log_c;
 }
 
-// Diagnostic phase stamp (only when a.stamps is set): wave 0 of the workgroup records the shader
-// clock after draining its own memory counters, so the differences are phase durations.
-#define STAMP(slot)                                                                     \
-    do {                                                                                \
-        if (a.stamps && tid == 0 && w == blockIdx.x + gridDim.x) {                      \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
-            a.stamps[(size_t)blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memtime();  \
-        }                                                                               \
+#ifdef STARKHIP_STAMPS
+// timing instrumentation (debug builds only): wave 0 of every workgroup records the 100 MHz
+// wall clock at the end of each phase
+__device__ unsigned long long g_stamps[2][8192][16];
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[a.in_raw ? 1 : 0][blockIdx.x][i] = wall_clock64(); \
     } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 template <int LOGT>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
+    using G = TileGeom<LOGT>;
     constexpr uint32_t T = 1u << LOGT, Q = T / 4, LOGQ = LOGT - 2;
     constexpr int ROUNDS = (LOGT + 1) / 2;
+    constexpr int LW = G::LW;
     extern __shared__ uint32_t lds[];
 
     const uint32_t log_c = a.log_c, C = 1u << log_c;
-    const uint32_t Tp = T + tile_pad29(log_c);
+    const uint32_t Tp = G::ROW + tile_pad29(log_c);
     const uint32_t plane = Tp << log_c;
     const uint32_t tid = threadIdx.x;
     const uint32_t in_w = a.in_raw ? 12u : 8u, out_w = a.out_raw ? 12u : 8u;
-
-    // Spread the workgroups' start times over one tile period so that across the chip (and
-    // between the workgroups sharing a CU) load, compute and store phases overlap instead of
-    // every workgroup hitting HBM at the same moment.
-    if (a.stagger_cycles) {
-        const uint32_t delay = (uint32_t)(((uint64_t)((blockIdx.x * 2654435761u) >> 8) * a.stagger_cycles) >> 24);
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(32);
-    }
-
-    const uint64_t total = (uint64_t)a.tiles * a.polys;
-#pragma unroll 1
-    for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    // Work item -> (tile, polynomial). Workgroups are dealt round-robin over the 8 XCDs, each with
+    // its own L2. With the grouped order, the workgroups that share an L2 take 2^grp_log adjacent
+    // tiles (whose strided 64..96-byte pieces complete each other's 128-byte lines) of every
+    // polynomial in turn (which re-use the same rows of the inter-pass twiddle table), while the
+    // chip as a whole still sweeps memory front to back.
     uint32_t tau, pidx;
-    if (a.xcd_map) {  // tiles is a multiple of 8: items w, w+8, w+16.. (one XCD) walk the polynomials of one tile
-        const uint64_t q = w >> 3;
-        pidx = (uint32_t)(q % a.polys);
-        tau = (uint32_t)(q / a.polys) * 8u + ((uint32_t)w & 7u);
+    if (a.grp_log) {
+        const uint32_t g = a.grp_log - 1, xcd = blockIdx.x & 7u, s = blockIdx.x >> 3, s2 = s >> g;
+        pidx = s2 % a.polys;
+        tau = ((((s2 / a.polys) << 3) | xcd) << g) | (s & ((1u << g) - 1u));
     } else {
-        tau = (uint32_t)(w % a.tiles);
-        pidx = (uint32_t)(w / a.tiles);
+        tau = blockIdx.x % a.tiles;
+        pidx = blockIdx.x / a.tiles;
     }
     const uint32_t hi = tau >> a.dsh, lo = tau & a.dmask;
     const uint64_t poly = (uint64_t)pidx * a.poly_stride;
-    if (w != blockIdx.x) __syncthreads();  // the previous item's last LDS reads are done
-    STAMP(0);
 
-    uint32_t ns_log = 0;
-    F29 carry_keep;
-#pragma unroll
-    for (int l = 0; l < 9; l++) carry_keep.l[l] = tid + l;
-#pragma unroll 1
-    for (int round = 0; round < ROUNDS; round++) {
-        const bool first = round == 0, last = round == ROUNDS - 1;
-        const bool cfast = last ? a.store_cfast : a.load_cfast;
-        uint32_t c, j;
+    // LDS dword offset (within a limb plane) of position p of tile c
+    auto at = [&](uint32_t c, uint32_t p) -> uint32_t {
+        return c * Tp + (p & (G::W - 1)) * G::SB + swz(p >> LW);
+    };
+    // lane orders: "edge" = as the global access wants it (tile index fastest, or element fastest),
+    // "local" = wavefront w of tile c runs butterflies j = lane * W + w
+    auto edge_map = [&](bool cfast, uint32_t& c, uint32_t& j) {
         if (cfast) {
             c = tid & (C - 1);
             j = tid >> log_c;
@@ -122,13 +138,53 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             c = tid >> LOGQ;
             j = tid & (Q - 1);
         }
-        const bool valid = (uint64_t)lo * C + c < a.c_limit;
-        const uint32_t row = c * Tp;
+    };
+    auto local_map = [&](uint32_t& c, uint32_t& j) {
+        if (Q >= 64) {
+            const uint32_t wave = tid >> 6, lane = tid & 63u;
+            c = wave >> LW;
+            j = (lane << LW) | (wave & (G::W - 1));
+        } else {
+            c = tid >> LOGQ;
+            j = tid & (Q - 1);
+        }
+    };
+    // the element-fastest edge order coincides with the local order when a tile is one wavefront or less
+    const bool load_is_local = !a.load_cfast && LW == 0;
+    const bool store_local = a.store_local != 0;
 
+    uint32_t ns_log = 0;
+    STAMP(0);
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; round++) {
+        const bool first = round == 0, last = round == ROUNDS - 1;
+        // which lane order this round runs in
+        bool local;
+        uint32_t c, j;
+        if (first) {
+            local = load_is_local;
+            edge_map(a.load_cfast, c, j);
+        } else if (last && !store_local) {
+            local = !a.store_cfast && LW == 0;
+            edge_map(a.store_cfast, c, j);
+        } else if (ns_log >= (uint32_t)LW) {
+            local = true;
+            local_map(c, j);
+        } else {
+            local = false;
+            edge_map(a.load_cfast, c, j);
+        }
+        const bool valid = (uint64_t)lo * C + c < a.c_limit;
+
+        // the first of the round's three twiddles w_T^(r * (j mod Ns) * T/(4 Ns)) is requested before
+        // the LDS reads so that both latencies overlap
+        F29 tw1;
+        const uint32_t e = ns_log > 0 ? (j & ((1u << ns_log) - 1u)) << (LOGQ - ns_log) : 0u;
+        if (ns_log > 0) tw1 = f29_load_raw(a.W + 12 * (size_t)e);
         F29 x0, x1, x2, x3;
         if (first) {
-            if (valid && !(a.ablate & 4)) {
-                const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
+            if (valid) {
+                const uint32_t* src = a.in + in_w * ((a.abl & 1 ? 0 : poly) + hi * a.inA + (a.abl & 1 ? lo & 7 : lo) * a.inB + c * a.inC);
                 const uint64_t s = (uint64_t)in_w * a.inS;
                 if (a.in_raw) {
                     x0 = f29_load_raw(src + s * j);
@@ -143,85 +199,73 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int l = 0; l < 9; l++) x0.l[l] = x1.l[l] = x2.l[l] = x3.l[l] = (a.ablate & 4) ? (tid * 2654435761u + l) >> 4 : 0;
+                for (int l = 0; l < 9; l++) x0.l[l] = x1.l[l] = x2.l[l] = x3.l[l] = 0;
             }
-        } else if (a.ablate & 2) {
-            x0 = x1 = x2 = x3 = carry_keep;
         } else {
-            x0 = lds_get29(lds, plane, row + j);
-            x1 = lds_get29(lds, plane, row + j + Q);
-            x2 = lds_get29(lds, plane, row + j + 2 * Q);
-            x3 = lds_get29(lds, plane, row + j + 3 * Q);
+            x0 = lds_get29(lds, plane, at(c, j));
+            x1 = lds_get29(lds, plane, at(c, j + Q));
+            x2 = lds_get29(lds, plane, at(c, j + 2 * Q));
+            x3 = lds_get29(lds, plane, at(c, j + 3 * Q));
+        }
+        // Is the exchange that follows this round confined to each wavefront's own sub-image?
+        // (this round and the next both run in the local lane order, and Ns >= W keeps the low bits of j)
+        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !store_local && !(!a.store_cfast && LW == 0);
+        const uint32_t ns_next = ((LOGT & 1) && first) ? 1u : ns_log + 2;
+        const bool out_local = !last && local && ns_log >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
+        if (!first) {
+            // inputs are in registers. If other wavefronts will overwrite them (cross-wave exchange)
+            // every wavefront must have finished reading first; a wave-local exchange only needs the
+            // compiler to keep this wavefront's own LDS order.
+            if (out_local) __builtin_amdgcn_wave_barrier();
+            else if (!last) __syncthreads();
         }
 
-        if (first) STAMP(1);
-        else STAMP(2 + 4 * round);
-        if (a.ablate & 16) {  // timing only: the pass's memory traffic without its arithmetic
-            if (valid) {
-                uint32_t* dst = a.out + out_w * (poly + hi * a.outA + lo * a.outB + c * a.outC);
-                const uint64_t s = (uint64_t)out_w * a.outS;
-                if (a.out_raw) {
-                    f29_store_raw(dst + s * j, x0);
-                    f29_store_raw(dst + s * (j + Q), x1);
-                    f29_store_raw(dst + s * (j + 2 * Q), x2);
-                    f29_store_raw(dst + s * (j + 3 * Q), x3);
-                } else {
-                    Fe t;
-#pragma unroll
-                    for (int l = 0; l < 8; l++) t.l[l] = x0.l[l] ^ x1.l[l];
-                    fe_store(dst + s * j, t);
-                    fe_store(dst + s * (j + Q), t);
-                    fe_store(dst + s * (j + 2 * Q), t);
-                    fe_store(dst + s * (j + 3 * Q), t);
-                }
-            }
-            break;
-        }
         if ((LOGT & 1) && first) {
             // radix-2 level on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
             F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
-            lds_put29(lds, plane, row + 2 * j, y0);
-            lds_put29(lds, plane, row + 2 * j + 1, y1);
-            lds_put29(lds, plane, row + 2 * (j + Q), y2);
-            lds_put29(lds, plane, row + 2 * (j + Q) + 1, y3);
-            __syncthreads();
+            lds_put29(lds, plane, at(c, 2 * j), y0);
+            lds_put29(lds, plane, at(c, 2 * j + 1), y1);
+            lds_put29(lds, plane, at(c, 2 * (j + Q)), y2);
+            lds_put29(lds, plane, at(c, 2 * (j + Q) + 1), y3);
+            if (out_local) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();
             ns_log = 1;
             continue;
         }
 
         if (ns_log > 0) {
-            // the three twiddled inputs come out of the multiplier tight; the untwiddled one
-            // is brought back to 29-bit limbs by a carry pass
-            const uint32_t e = (a.ablate & 1) ? 0u : (j & ((1u << ns_log) - 1u)) << (LOGQ - ns_log);
-            x1 = f29_mul(x1, f29_load_raw(a.W + 12 * (size_t)e));
-            x2 = f29_mul(x2, f29_load_raw(a.W + 12 * (size_t)(2 * e)));
-            x3 = f29_mul(x3, f29_load_raw(a.W + 12 * (size_t)(3 * e)));
+            // the three twiddled inputs come out of the multiplier tight; the untwiddled one is brought
+            // back to 29-bit limbs by a carry pass. Each later twiddle is requested one multiplication
+            // ahead of its use.
+            F29 tw2 = f29_load_raw(a.W + 12 * (size_t)(2 * e));
+            x1 = f29_mul(x1, tw1);
+            F29 tw3 = f29_load_raw(a.W + 12 * (size_t)(3 * e));
+            x2 = f29_mul(x2, tw2);
+            x3 = f29_mul(x3, tw3);
             x0 = f29_carry(x0);
         }
         // radix-4 butterfly, I = w_T^(T/4); every subtrahend is tight or a sum of two tight values
-        STAMP(3 + 4 * round);
         F29 y0, y1, y2, y3;
+        const uint32_t d = ((j >> ns_log) << (ns_log + 2)) + (j & ((1u << ns_log) - 1u));
         {
             F29 a0 = f29_add(x0, x2), a1 = f29_sub(x0, x2), a2 = f29_add(x1, x3);
-            F29 a3 = f29_mul(f29_sub(x1, x3), f29_load_raw(a.W + 12 * (size_t)Q));
             y0 = f29_add(a0, a2);
-            y1 = f29_add(a1, a3);
             y2 = f29_sub2(a0, a2);
+            if (!last) {  // these two do not wait for the multiplication by I
+                lds_put29(lds, plane, at(c, d), y0);
+                lds_put29(lds, plane, at(c, d + (2u << ns_log)), y2);
+            }
+            F29 a3 = f29_mul(f29_sub(x1, x3), f29_load_raw(a.W + 12 * (size_t)Q));
+            y1 = f29_add(a1, a3);
             y3 = f29_sub(a1, a3);
         }
-
-        STAMP(4 + 4 * round);
-        if (!last && (a.ablate & 2)) {
-            carry_keep = f29_carry(f29_add(f29_add(y0, y1), f29_add(y2, y3)));
-        } else if (!last) {
-            const uint32_t d = row + ((j >> ns_log) << (ns_log + 2)) + (j & ((1u << ns_log) - 1u));
-            if (!first) __syncthreads();
-            lds_put29(lds, plane, d, y0);
-            lds_put29(lds, plane, d + (1u << ns_log), y1);
-            lds_put29(lds, plane, d + (2u << ns_log), y2);
-            lds_put29(lds, plane, d + (3u << ns_log), y3);
-            __syncthreads();
-        } else if (valid && (!(a.ablate & 8) || y0.l[0] == 0xFFFFFFFFu)) {
+        if (!last) {
+            lds_put29(lds, plane, at(c, d + (1u << ns_log)), y1);
+            lds_put29(lds, plane, at(c, d + (3u << ns_log)), y3);
+            if (out_local) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();  // the next round's inputs come from other wavefronts
+            STAMP(1 + round);
+        } else if (valid) {
             if (a.TW || a.has_scale) {
                 Fe s;
 #pragma unroll
@@ -232,7 +276,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 y2 = f29_mul(y2, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS)) : s));
                 y3 = f29_mul(y3, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS)) : s));
             }
-            uint32_t* dst = a.out + out_w * (poly + hi * a.outA + lo * a.outB + c * a.outC);
+            uint32_t* dst = a.out + out_w * ((a.abl & 2 ? 0 : poly) + hi * a.outA + (a.abl & 2 ? lo & 7 : lo) * a.outB + c * a.outC);
             const uint64_t s = (uint64_t)out_w * a.outS;
             if (a.out_raw) {
                 f29_store_raw(dst + s * j, y0);
@@ -246,15 +290,25 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 fe_store(dst + s * (j + 3 * Q), f29_to_fe(y3));
             }
         }
-        STAMP(5 + 4 * round);
         ns_log += 2;
     }
-    }  // work items
+#ifdef STARKHIP_STAMPS
+    STAMP(ROUNDS);
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(ROUNDS + 1);
+#endif
 }
+
+#ifdef STARKHIP_STAMPS
+extern "C" int stark_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
 
 template <int LOGT>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
+    if (const char* x = getenv("STARKHIP_LDS_EXTRA")) lds += (size_t)atoi(x);  // occupancy experiments
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
     if (threads > 1024 || lds > 160 * 1024) return hipErrorInvalidConfiguration;
     static bool attr_set[64] = {};  // per device: dynamic LDS above 64 KiB must be opted into
@@ -267,31 +321,17 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
         if (e != hipSuccess) return e;
         if (dev < 64) attr_set[dev] = true;
     }
-    static int cus[64] = {};
-    int ncu = dev < 64 ? cus[dev] : 0;
-    if (ncu == 0) {
-        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-        if (dev < 64) cus[dev] = ncu;
-    }
-    // resident workgroups per CU: LDS, and four waves per SIMD (the kernel's register budget)
-    unsigned per_cu = (unsigned)(160 * 1024 / lds);
-    if (per_cu > 1024 / threads) per_cu = 1024 / threads;
-    if (per_cu < 1) per_cu = 1;
     NttPassArgs b = a;
+    static const int sl = getenv("STARKHIP_STORE_LOCAL") ? atoi(getenv("STARKHIP_STORE_LOCAL")) : 0;
+    static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 3;  // log2 of tiles per L2 group, -1 = off
+    b.store_local = (uint32_t)sl;
+    b.abl = getenv("STARKHIP_ABL") ? atoi(getenv("STARKHIP_ABL")) : 0;
     b.tiles = tiles;
     b.polys = polys;
-    b.xcd_map = (getenv("STARKHIP_XCDMAP") && tiles % 8 == 0 && tiles >= 8) ? 1u : 0u;
-    const uint64_t total = (uint64_t)tiles * polys;
-    // One work item per workgroup unless a persistent grid is asked for (STARKHIP_PERSISTENT=1):
-    // on this kernel the hardware dispatcher's refill of finished slots measured faster than a
-    // resident loop over items.
-    static const bool persistent = getenv("STARKHIP_PERSISTENT") && atoi(getenv("STARKHIP_PERSISTENT")) > 0;
-    uint64_t grid = persistent ? (uint64_t)ncu * per_cu : total;
-    if (grid > total) grid = total;
-    if (grid > 0x7FFFFFFFull) grid = 0x7FFFFFFFull;
-    if (total < 4 * grid) b.stagger_cycles = 0;  // too few items per workgroup for the stagger to pay
-    hipLaunchKernelGGL(ntt29_pass_kernel<LOGT>, dim3((unsigned)grid), dim3(threads), lds, stream, b);
+    b.grp_log = 0;
+    if (grp >= 0 && tiles % (8u << grp) == 0) b.grp_log = (uint32_t)grp + 1;
+    if ((uint64_t)tiles * polys >= (1ull << 31)) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(ntt29_pass_kernel<LOGT>, dim3(tiles * polys), dim3(threads), lds, stream, b);
     return hipGetLastError();
 }
 
