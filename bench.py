@@ -39,6 +39,19 @@ PEAK_VALU_TOPS = 78.6            # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, ful
 PEAK_HBM_GBPS = 8000.0
 
 
+def measured_traffic(kernel: str, units: float):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter summary
+    (FETCH_SIZE corrected x2 for gfx950's wide-read tally, plus WRITE_SIZE), scaled to the
+    `units` (polynomials or branches) one launch of this run processes. None if not collected."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)[kernel]
+        return t["hbm_bytes_per_unit"] * units
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_merkle_case(n: int, depth: int, seed: int, corrupt_every: int = 100):
     """One real BLAKE2s tree with 2^depth 32-byte leaves (hashlib) and n uniformly random queries
     against it; every `corrupt_every`-th branch gets one flipped witness bit (expected reject)."""
@@ -224,7 +237,7 @@ def main():
                 "achieved": ntt_tops, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (32-bit integer lane-ops)",
                 "frac": ntt_tops / PEAK_VALU_TOPS, "launch_us": launch_s * 1e6, "launches_per_step": launches,
                 "hbm_achieved_GBps": bytes_per_launch / launch_s * 1e-9, "hbm_frac": bytes_per_launch / launch_s * 1e-9 / PEAK_HBM_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic("ntt29_pass_kernel<%d>" % ((log_n + 1) // 2), B / (launches / passes)) if passes == 2 else None,
             },
             "merkle": {
                 "metric": "Merkle branch verifications/sec (depth %d)" % args.depth, "value": mk_per_s, "unit": "branches/s",
@@ -235,7 +248,8 @@ def main():
                              "frac": mk_ops / (dev_ms_mk * 1e-3) * 1e-12 / PEAK_VALU_TOPS,
                              "launch_us": dev_ms_mk * 1e3,
                              "hbm_achieved_GBps": mk_bytes / (dev_ms_mk * 1e-3) * 1e-9,
-                             "hbm_frac": mk_bytes / (dev_ms_mk * 1e-3) * 1e-9 / PEAK_HBM_GBPS, "traffic": None},
+                             "hbm_frac": mk_bytes / (dev_ms_mk * 1e-3) * 1e-9 / PEAK_HBM_GBPS,
+                             "traffic": measured_traffic("merkle_verify_kernel<true>", args.merkle_n)},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -23,15 +23,22 @@ namespace starkhip {
 // 32 distinct banks per 32-lane group; without it the writes are up to 4-way conflicted.
 __device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 2) & 31u); }
 
+// An element's nine limbs are adjacent in LDS (slot * 9 + limb): one address per element, the
+// limbs at immediate offsets, two per ds_read2/ds_write2. 9 is odd, so slots that differ mod
+// 64 stay on different banks.
 __device__ __forceinline__ void lds_put29(uint32_t* lds, uint32_t plane, uint32_t off, const F29& v) {
+    (void)plane;
+    uint32_t* q = lds + off * 9;
 #pragma unroll
-    for (int l = 0; l < 9; l++) lds[l * plane + off] = v.l[l];
+    for (int l = 0; l < 9; l++) q[l] = v.l[l];
 }
 
 __device__ __forceinline__ F29 lds_get29(const uint32_t* lds, uint32_t plane, uint32_t off) {
+    (void)plane;
+    const uint32_t* q = lds + off * 9;
     F29 v;
 #pragma unroll
-    for (int l = 0; l < 9; l++) v.l[l] = lds[l * plane + off];
+    for (int l = 0; l < 9; l++) v.l[l] = q[l];
     return v;
 }
 
