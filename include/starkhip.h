@@ -101,6 +101,30 @@ int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batc
 int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
                         const uint32_t root_of_unity[8], int inverse, void* stream);
 
+/*
+ * Local steps of one transform sharded over several GPUs. A transform of n = n1 * n2 points
+ * (input index j = j1 + n1*j2, output index k = k1*n2 + k2) is
+ *   (A) for every j1: an n2-point transform over j2        -> stark_ntt_batch_dev, root^n1
+ *   (B) multiply element (j1, k2) by root^(j1*k2)          -> stark_twiddle_mul_dev
+ *   (C) for every k2: an n1-point transform over j1        -> stark_ntt_batch_dev, root^n2
+ * which is what the recursion of _fft (reference src/fft.rs:37-61) computes, regrouped; a rank
+ * that owns a range of j1 runs (A) and (B) locally, the ranks exchange blocks (all-to-all), and
+ * the owner of a range of k2 runs (C). The exchange itself is the host layer's (RCCL through
+ * torch.distributed); these two entry points are the device work either side of it. They have
+ * no counterpart in the reference, which is single-threaded.
+ */
+
+/* d_data[r][c] *= w^((row0 + r) * (col0 + c)) for a row-major rows x cols block of canonical or
+ * non-canonical elements (outputs canonical); w = root_of_unity, or its inverse if inverse != 0;
+ * root_of_unity must have order exactly 2^log_order (else STARK_ERR_INVALID). In place. */
+int stark_twiddle_mul_dev(stark_ctx* ctx, void* d_data, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
+                          unsigned log_order, const uint32_t root_of_unity[8], int inverse, void* stream);
+
+/* d_out[b][a][k] = d_in[a][b][k] for a x b blocks of `chunk` consecutive 32-byte elements
+ * (chunk == 1 is a plain transpose). Packs the send blocks of an all-to-all and transposes the
+ * received ones. d_in and d_out must not overlap; a <= 2097120 when chunk == 1. */
+int stark_permute3_dev(stark_ctx* ctx, const void* d_in, void* d_out, size_t a, size_t b, size_t chunk, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Merkle — replaces the bodies of ProofBranch::verify (reference src/merkle_tree.rs:119-171)
  * and the loop of MultiProof::verify (src/merkle_tree.rs:25-44).

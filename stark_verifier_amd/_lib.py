@@ -27,7 +27,7 @@ EXPORTS = [
     "stark_version", "stark_ctx_create", "stark_ctx_destroy", "stark_last_error", "stark_ctx_stream",
     "stark_ctx_synchronize", "stark_fft_inv", "stark_fft", "stark_ntt_batch", "stark_ntt_batch_dev",
     "stark_merkle_verify_batch", "stark_merkle_verify_batch_dev", "stark_field_op",
-    "stark_fill_random_field_dev",
+    "stark_fill_random_field_dev", "stark_twiddle_mul_dev", "stark_permute3_dev",
 ]
 
 
@@ -81,6 +81,10 @@ def load() -> ctypes.CDLL:
     L.stark_field_op.restype = i32
     L.stark_fill_random_field_dev.argtypes = [vp, vp, sz, u64, vp]
     L.stark_fill_random_field_dev.restype = i32
+    L.stark_twiddle_mul_dev.argtypes = [vp, vp, sz, sz, u64, u64, ctypes.c_uint, vp, i32, vp]
+    L.stark_twiddle_mul_dev.restype = i32
+    L.stark_permute3_dev.argtypes = [vp, vp, vp, sz, sz, sz, vp]
+    L.stark_permute3_dev.restype = i32
     _lib = L
     return L
 

@@ -44,6 +44,7 @@ struct stark_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<std::unique_ptr<NttPlan>> plans;
+    std::vector<std::unique_ptr<NttPlan>> shard_tables;  // two-level power tables of stark_twiddle_mul_dev (passes unused)
     void* scratch = nullptr;  // multi-pass intermediate
     size_t scratch_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -469,6 +470,7 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->plans) free_plan(p.get());
+    for (auto& p : ctx->shard_tables) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
     (void)hipStreamDestroy(ctx->stream);
@@ -482,6 +484,52 @@ void* stark_ctx_stream(stark_ctx* ctx) { return ctx ? (void*)ctx->stream : nullp
 int stark_ctx_synchronize(stark_ctx* ctx) {
     if (!ctx) return STARK_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+int stark_twiddle_mul_dev(stark_ctx* ctx, void* d_data, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
+                          unsigned log_order, const uint32_t root_of_unity[8], int inverse, void* stream) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || (rows && cols && !d_data)) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_order > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_order %u above 30", log_order);
+    if (rows && cols > (~(size_t)0) / rows) return fail(ctx, STARK_ERR_INVALID, "rows * cols overflows");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    U256 r = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(r, log_order))
+        return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_order);
+    NttPlan* tab = nullptr;
+    for (auto& p : ctx->shard_tables)
+        if (p->log_n == log_order && p->inverse == (inverse != 0) && hostfe::eq(p->root, r)) tab = p.get();
+    const unsigned lo_bits = (log_order + 1) / 2, hi_bits = log_order - lo_bits;
+    if (!tab) {
+        auto plan = std::make_unique<NttPlan>();
+        plan->log_n = log_order;
+        plan->root = r;
+        plan->inverse = inverse != 0;
+        const U256 w = inverse ? hostfe::pow_u64(r, ((uint64_t)1 << log_order) - 1) : r;
+        const U256 one = hostfe::from_u64(1);
+        uint32_t *lo, *hi;
+        int rc;
+        if ((rc = make_table(ctx, plan.get(), w, (size_t)1 << lo_bits, 0, one, &lo)) != STARK_OK ||
+            (rc = make_table(ctx, plan.get(), hostfe::pow_u64(w, (uint64_t)1 << lo_bits), (size_t)1 << hi_bits, 0, one,
+                             &hi)) != STARK_OK) {
+            free_plan(plan.get());
+            return rc;
+        }
+        tab = plan.get();
+        ctx->shard_tables.push_back(std::move(plan));
+    }
+    HIP_TRY(ctx, launch_twiddle_mul((uint32_t*)d_data, rows, cols, row0, col0, log_order, lo_bits,
+                                    (const uint32_t*)tab->tables[0], (const uint32_t*)tab->tables[1],
+                                    stream ? (hipStream_t)stream : ctx->stream));
+    return STARK_OK;
+}
+
+int stark_permute3_dev(stark_ctx* ctx, const void* d_in, void* d_out, size_t a, size_t b, size_t chunk, void* stream) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (a && b && chunk && (!d_in || !d_out || d_in == d_out)) return fail(ctx, STARK_ERR_INVALID, "null or aliased buffers");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_permute3(d_in, d_out, a, b, chunk, stream ? (hipStream_t)stream : ctx->stream));
     return STARK_OK;
 }
 

@@ -61,4 +61,10 @@ hipError_t launch_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_
 // synthetic canonical field elements from SplitMix64(seed), 4 draws per element
 hipError_t launch_fill_random_field(uint32_t* out, size_t n, uint64_t seed, hipStream_t stream);
 
+// sharded-transform helpers (shard.hip)
+hipError_t launch_twiddle_mul(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0,
+                              uint32_t log_order, uint32_t lo_bits, const uint32_t* lo, const uint32_t* hi,
+                              hipStream_t stream);
+hipError_t launch_permute3(const void* in, void* out, uint64_t A, uint64_t B, uint64_t chunk, hipStream_t stream);
+
 }  // namespace starkhip

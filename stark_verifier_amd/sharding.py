@@ -48,3 +48,142 @@ def gather_accept_bits(local_accept, total: int, device=None):
         lo, hi = shard_range(total, r, world)
         out[lo:hi] = p[: hi - lo].cpu().numpy()
     return out
+
+
+# ---- one transform sharded over several ranks -------------------------------------------------
+#
+# n = n1 * n2, input index j = j1 + n1*j2, output index k = k1*n2 + k2:
+#   X[k1*n2 + k2] = sum_j1 w_n1^(j1*k1) * [ w^(j1*k2) * sum_j2 x[j1 + n1*j2] * w_n2^(j2*k2) ]
+# which is the recursion of the reference's _fft (src/fft.rs:37-61) regrouped into two stages of
+# independent transforms. Rank g owns a range of j1 for stage A and the twiddle step, a range of
+# k2 for stage C; one all-to-all moves the data between the two ownerships. Contiguous ("blocked")
+# input or output costs one more all-to-all each, because a contiguous slice of x is a range of
+# j2 (not j1) and a contiguous slice of X is a range of k1 (not k2).
+
+class HipLocalOps:
+    """Device work of the sharded transform through the C ABI, on torch CUDA tensors of shape
+    [elements, 8] int32. The library's launches, torch's allocations / copies and the collectives
+    all go to the context's own stream, which torch sees as an ExternalStream; `stream_context`
+    makes it current and orders it after, and the caller's stream after, the work around it."""
+
+    def __init__(self, ctx=None):
+        import torch
+        from . import _lib
+        self.ctx = ctx or _lib.default_context()
+        self.tstream = torch.cuda.ExternalStream(self.ctx.stream)
+
+    def stream_context(self):
+        import contextlib
+        import torch
+
+        @contextlib.contextmanager
+        def cm():
+            outer = torch.cuda.current_stream()
+            self.tstream.wait_stream(outer)
+            with torch.cuda.stream(self.tstream):
+                yield
+            outer.wait_stream(self.tstream)
+        return cm()
+
+    def _stream(self):
+        return self.tstream.cuda_stream
+
+    def ntt_batch(self, t, log_m: int, batch: int, root: int, inverse: bool):
+        from . import fft
+        fft.ntt_batch_dev(t.data_ptr(), t.data_ptr(), log_m, batch, root, inverse, self.ctx, self._stream())
+
+    def twiddle_mul(self, t, rows: int, cols: int, row0: int, col0: int, log_order: int, root: int, inverse: bool):
+        from . import fft
+        r = fft._limbs(root % fft.MODULUS)
+        self.ctx.check(self.ctx.lib.stark_twiddle_mul_dev(self.ctx.handle, t.data_ptr(), rows, cols, row0, col0,
+                                                          log_order, fft._ptr(r), int(bool(inverse)), self._stream() or None))
+
+    def permute3(self, t, a: int, b: int, chunk: int):
+        import torch
+        out = torch.empty_like(t)
+        self.ctx.check(self.ctx.lib.stark_permute3_dev(self.ctx.handle, t.data_ptr(), out.data_ptr(), a, b, chunk,
+                                                       self._stream() or None))
+        return out
+
+
+def _all_to_all(t, group):
+    """Equal-split all-to-all of a [world * m, 8] tensor along dim 0. Device tensors go through RCCL
+    when the group's backend is "nccl"; any other backend (gloo) is staged through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        src = t.cpu()
+        dst = torch.empty_like(src)
+        dist.all_to_all_single(dst, src, group=group)
+        return dst.to(t.device)
+    out = torch.empty_like(t)
+    dist.all_to_all_single(out, t.contiguous(), group=group)
+    return out
+
+
+def _redistribute(t, rows: int, cols: int, world: int, group, ops):
+    """t is this rank's [rows][cols] slab of a [world*rows][cols] matrix split by rows. Returns this
+    rank's [cols/world][world*rows] slab of the transposed matrix (split by rows again)."""
+    packed = ops.permute3(t, rows, world, cols // world) if world > 1 else t   # [dest][rows][cols/world]
+    got = _all_to_all(packed, group)                                              # [src][rows][cols/world]
+    return ops.permute3(got, world * rows, cols // world, 1)                      # [cols/world][world*rows]
+
+
+def sharded_split(log_n: int):
+    """(log n1, log n2) used by ntt_sharded."""
+    return log_n // 2, log_n - log_n // 2
+
+
+def ntt_sharded(x_local, log_n: int, root_of_unity: int, inverse: bool = False, group=None,
+                in_layout: str = "blocked", out_layout: str = "blocked", ops=None):
+    """One 2^log_n-point transform whose data is spread over the ranks of `group`.
+
+    x_local: this rank's [n/world, 8] int32 tensor of limbs.
+      in_layout "blocked": the contiguous slice x[rank*n/world : (rank+1)*n/world].
+      in_layout "strided": row-major [n1/world][n2] with element (a, j2) = x[(rank*n1/world + a) + n1*j2].
+    Returns this rank's [n/world, 8] tensor of the result X (fft_inv semantics if `inverse`):
+      out_layout "blocked": X[rank*n/world : (rank+1)*n/world].
+      out_layout "strided": row-major [n2/world][n1] with element (b, k1) = X[k1*n2 + rank*n2/world + b].
+    "strided" on both sides needs a single all-to-all; each "blocked" side adds one.
+    world must divide both n1 = 2^(log_n // 2) and n2 = n / n1. With no process group it runs the
+    same steps on one rank.
+    """
+    import contextlib
+    import torch.distributed as dist
+
+    if in_layout not in ("blocked", "strided") or out_layout not in ("blocked", "strided"):
+        raise ValueError("layouts are 'blocked' or 'strided'")
+    ops = ops or HipLocalOps()
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    l1, l2 = sharded_split(log_n)
+    n1, n2, n = 1 << l1, 1 << l2, 1 << log_n
+    if n1 % world or n2 % world:
+        raise ValueError(f"world size {world} must divide n1={n1} and n2={n2}")
+    if tuple(x_local.shape) != (n // world, 8):
+        raise ValueError(f"x_local must have shape ({n // world}, 8), got {tuple(x_local.shape)}")
+    from .fft import MODULUS
+    w = root_of_unity % MODULUS
+    r1, r2 = n1 // world, n2 // world
+
+    with getattr(ops, "stream_context", contextlib.nullcontext)():
+        if in_layout == "blocked":
+            # local slab [j2 in my range][j1] -> [j1 in my range][j2]
+            s = _redistribute(x_local, r2, n1, world, group, ops)
+        else:
+            s = x_local.clone()
+        ops.ntt_batch(s, l2, r1, pow(w, n1, MODULUS), inverse)                  # stage A over j2
+        ops.twiddle_mul(s, r1, n2, rank * r1, 0, log_n, w, inverse)             # w^(+-j1*k2)
+        u = _redistribute(s, r1, n2, world, group, ops)                         # [k2 in my range][j1]
+        ops.ntt_batch(u, l1, r2, pow(w, n2, MODULUS), inverse)                  # stage C over j1
+        if out_layout == "blocked":
+            u = _redistribute(u, r2, n1, world, group, ops)                     # [k1 in my range][k2]
+        if hasattr(u, "record_stream") and u.is_cuda:
+            import torch
+            u.record_stream(torch.cuda.current_stream())
+    return u

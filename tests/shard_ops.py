@@ -1,0 +1,33 @@
+"""CPU stand-in for the device steps of the sharded transform, built on the oracle: lets the
+orchestration in stark_verifier_amd.sharding (index maps, packing, all-to-all) be checked with
+gloo on machines without a GPU. Test infrastructure only."""
+import numpy as np
+import torch
+
+import oracle
+
+P = oracle.P
+
+
+class OracleLocalOps:
+    def ntt_batch(self, t, log_m, batch, root, inverse):
+        m = 1 << log_m
+        a = t.numpy().view(np.uint32).reshape(batch, m, 8)
+        for b in range(batch):
+            a[b] = oracle.fft_inv(a[b], root) if inverse else oracle.fft_fwd(a[b], root)
+
+    def twiddle_mul(self, t, rows, cols, row0, col0, log_order, root, inverse):
+        w = pow(root, P - 2, P) if inverse else root
+        a = t.numpy().view(np.uint32).reshape(rows * cols, 8)
+        vals = oracle.limbs_to_ints(a)
+        out = []
+        for r in range(rows):
+            base = pow(w, row0 + r, P)
+            tw = pow(base, col0, P)
+            for c in range(cols):
+                out.append(vals[r * cols + c] * tw % P)
+                tw = tw * base % P
+        a[:] = oracle.ints_to_limbs(out)
+
+    def permute3(self, t, a, b, chunk):
+        return t.reshape(a, b, chunk, 8).permute(1, 0, 2, 3).contiguous().reshape(-1, 8)

@@ -1,0 +1,177 @@
+"""One transform sharded over ranks (stark_verifier_amd.sharding.ntt_sharded): every layout
+combination must reassemble to the oracle's transform of the whole vector, bit for bit.
+
+CPU: 1 rank and 2 ranks over gloo with the oracle standing in for the device steps (checks the
+orchestration). GPU: the same through the HIP library, 1 rank in-process and 2 ranks (gloo,
+staged exchange) sharing the one card."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from shard_ops import OracleLocalOps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = oracle.P
+
+
+def _expected_slices(X, log_n, world, layout):
+    """Per-rank [n/world, 8] arrays of the full result X in the given output layout."""
+    n = 1 << log_n
+    l1 = log_n // 2
+    n1, n2 = 1 << l1, n >> l1
+    if layout == "blocked":
+        return [X[r * n // world:(r + 1) * n // world] for r in range(world)]
+    M = X.reshape(n1, n2, 8)  # X[k1*n2 + k2]
+    r2 = n2 // world
+    return [np.ascontiguousarray(M[:, r * r2:(r + 1) * r2].transpose(1, 0, 2)).reshape(-1, 8) for r in range(world)]
+
+
+def _input_slices(x, log_n, world, layout):
+    n = 1 << log_n
+    l1 = log_n // 2
+    n1, n2 = 1 << l1, n >> l1
+    if layout == "blocked":
+        return [x[r * n // world:(r + 1) * n // world] for r in range(world)]
+    M = x.reshape(n2, n1, 8)  # x[j1 + n1*j2] at [j2][j1]
+    r1 = n1 // world
+    return [np.ascontiguousarray(M[:, r * r1:(r + 1) * r1].transpose(1, 0, 2)).reshape(-1, 8) for r in range(world)]
+
+
+@pytest.mark.parametrize("log_n", [4, 7, 10])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_single_rank_all_layouts_cpu(log_n, inverse):
+    from stark_verifier_amd.sharding import ntt_sharded
+    n = 1 << log_n
+    w = pow(7, (P - 1) >> log_n, P)
+    x = synth.field_elements(77 + log_n, n)
+    X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+    for li in ("blocked", "strided"):
+        for lo in ("blocked", "strided"):
+            xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy())
+            out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=OracleLocalOps())
+            assert np.array_equal(out.numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), (li, lo)
+
+
+def test_rejects_bad_world_or_shape():
+    from stark_verifier_amd.sharding import ntt_sharded
+    w = pow(7, (P - 1) >> 6, P)
+    with pytest.raises(ValueError):
+        ntt_sharded(torch.zeros((63, 8), dtype=torch.int32), 6, w, ops=OracleLocalOps())
+    with pytest.raises(ValueError):
+        ntt_sharded(torch.zeros((64, 8), dtype=torch.int32), 6, w, in_layout="cyclic", ops=OracleLocalOps())
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+root_dir, mode, log_n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+sys.path.insert(0, root_dir); sys.path.insert(0, os.path.join(root_dir, "tests"))
+import oracle, synth
+from test_sharded_ntt import _expected_slices, _input_slices
+from stark_verifier_amd.sharding import ntt_sharded
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+P = oracle.P
+n = 1 << log_n
+w = pow(7, (P - 1) >> log_n, P)
+x = synth.field_elements(4242, n)
+if mode == "hip":
+    import stark_verifier_amd as sv
+    from stark_verifier_amd.sharding import HipLocalOps
+    torch.cuda.set_device(0)
+    ops = HipLocalOps(sv.Context(0)); dev = "cuda"
+else:
+    from shard_ops import OracleLocalOps
+    ops = OracleLocalOps(); dev = "cpu"
+for inverse in (False, True):
+    X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+    for li in ("blocked", "strided"):
+        for lo in ("blocked", "strided"):
+            xin = torch.from_numpy(_input_slices(x, log_n, world, li)[rank].view(np.int32).copy()).to(dev)
+            out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=ops)
+            got = out.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, _expected_slices(X, log_n, world, lo)[rank]), (rank, inverse, li, lo)
+dist.barrier()
+if rank == 0:
+    print("ok")
+dist.destroy_process_group()
+"""
+
+
+def _run_ranks(tmp_path, world, mode, log_n):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, mode, str(log_n)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ok" in r.stdout
+
+
+def test_two_rank_gloo_sharded_transform_cpu(tmp_path):
+    _run_ranks(tmp_path, 2, "oracle", 8)
+
+
+def test_four_rank_gloo_sharded_transform_cpu(tmp_path):
+    _run_ranks(tmp_path, 4, "oracle", 6)
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [4, 9, 14, 16])
+def test_single_rank_hip_all_layouts(log_n):
+    from stark_verifier_amd.sharding import ntt_sharded
+    n = 1 << log_n
+    w = pow(7, (P - 1) >> log_n, P)
+    x = synth.field_elements(99 + log_n, n)
+    for inverse in (False, True):
+        X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+        for li in ("blocked", "strided"):
+            for lo in ("blocked", "strided"):
+                xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy()).cuda()
+                out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo)
+                assert np.array_equal(out.cpu().numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), (inverse, li, lo)
+
+
+@pytest.mark.gpu
+def test_twiddle_and_permute_kernels_against_numpy():
+    import stark_verifier_amd as sv
+    from stark_verifier_amd.sharding import HipLocalOps
+    from shard_ops import OracleLocalOps
+    ops, ref = HipLocalOps(), OracleLocalOps()
+    log_order = 11
+    w = pow(7, (P - 1) >> log_order, P)
+    for rows, cols, row0, col0 in ((3, 5, 0, 0), (16, 128, 48, 7), (1, 2048, 2047, 0), (37, 33, 1000, 1500)):
+        a = synth.field_elements(rows * cols + 1, rows * cols)
+        a[0] = 0xFFFFFFFF  # a non-canonical input must come out canonical
+        for inverse in (False, True):
+            t = torch.from_numpy(a.view(np.int32).copy()).cuda()
+            with ops.stream_context():
+                ops.twiddle_mul(t, rows, cols, row0, col0, log_order, w, inverse)
+            e = torch.from_numpy(a.view(np.int32).copy())
+            ref.twiddle_mul(e, rows, cols, row0, col0, log_order, w, inverse)
+            assert torch.equal(t.cpu(), e)
+    for A, B, chunk in ((1, 1, 1), (33, 65, 1), (64, 32, 1), (100, 7, 1), (3, 4, 5), (8, 2, 64), (5, 9, 2)):
+        t = torch.arange(A * B * chunk * 8, dtype=torch.int32).reshape(-1, 8)
+        with ops.stream_context():
+            got = ops.permute3(t.cuda(), A, B, chunk).cpu()
+        assert torch.equal(got, ref.permute3(t, A, B, chunk)), (A, B, chunk)
+    with pytest.raises(sv.InvalidArgument), ops.stream_context():
+        ops.twiddle_mul(torch.zeros((4, 8), dtype=torch.int32).cuda(), 2, 2, 0, 0, 10, w, False)  # wrong order
+
+
+@pytest.mark.gpu
+def test_two_rank_gloo_sharded_transform_hip(tmp_path):
+    _run_ranks(tmp_path, 2, "hip", 14)
