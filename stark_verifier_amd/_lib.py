@@ -15,7 +15,8 @@ except Exception:  # pragma: no cover - torch is optional for the C ABI itself
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+# STARKHIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("STARKHIP_LIB") or os.path.join(_HERE, "libstarkhip.so")
 
 STARK_OK = 0
 STARK_ERR_INVALID = -1

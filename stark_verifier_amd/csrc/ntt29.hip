@@ -89,6 +89,10 @@ size_t ntt29_pass_lds_bytes(int log_t, int log_c) {
     return 36 * row << log_c;
 }
 
+struct Quad29 {
+    F29 a, b, c, d;
+};
+
 #ifdef STARKHIP_STAMPS
 // timing instrumentation (debug builds only): wave 0 of every workgroup records the 100 MHz
 // wall clock at the end of each phase
@@ -160,11 +164,58 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     const bool load_is_local = !a.load_cfast && LW == 0;
     const bool store_local = a.store_local != 0;
 
+    // global -> registers for the lane's four inputs (first round; zeros for tiles past the end)
+    auto load_inputs = [&](uint32_t c, uint32_t j, bool valid) -> Quad29 {
+        F29 x0, x1, x2, x3;
+        if (valid) {
+            const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
+            const uint64_t s = (uint64_t)in_w * a.inS;
+            if (a.in_raw) {
+                x0 = f29_load_raw(src + s * j);
+                x1 = f29_load_raw(src + s * (j + Q));
+                x2 = f29_load_raw(src + s * (j + 2 * Q));
+                x3 = f29_load_raw(src + s * (j + 3 * Q));
+            } else {
+                x0 = f29_from_fe(fe_load(src + s * j));
+                x1 = f29_from_fe(fe_load(src + s * (j + Q)));
+                x2 = f29_from_fe(fe_load(src + s * (j + 2 * Q)));
+                x3 = f29_from_fe(fe_load(src + s * (j + 3 * Q)));
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < 9; l++) x0.l[l] = x1.l[l] = x2.l[l] = x3.l[l] = 0;
+        }
+        return Quad29{x0, x1, x2, x3};
+    };
+    // Is the exchange after a round confined to each wavefront's own sub-image? (the round and the
+    // next one both run in the local lane order, and Ns >= W keeps the low bits of j)
+    auto exchange_is_local = [&](int round, bool local, uint32_t ns_now, uint32_t ns_next) {
+        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !store_local && !(!a.store_cfast && LW == 0);
+        return round != ROUNDS - 1 && local && ns_now >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
+    };
+
+    constexpr bool ODD = (LOGT & 1) != 0;
     uint32_t ns_log = 0;
     STAMP(0);
+    if (ODD) {
+        // odd log2(T): one radix-2 level first, on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
+        uint32_t c, j;
+        edge_map(a.load_cfast, c, j);
+        const bool valid = (uint64_t)lo * C + c < a.c_limit;
+        const Quad29 q = load_inputs(c, j, valid);
+        const F29 &x0 = q.a, &x1 = q.b, &x2 = q.c, &x3 = q.d;
+        F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
+        lds_put29(lds, plane, at(c, 2 * j), y0);
+        lds_put29(lds, plane, at(c, 2 * j + 1), y1);
+        lds_put29(lds, plane, at(c, 2 * (j + Q)), y2);
+        lds_put29(lds, plane, at(c, 2 * (j + Q) + 1), y3);
+        if (exchange_is_local(0, load_is_local, 0, 1)) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+        ns_log = 1;
+    }
 #pragma unroll 1
-    for (int round = 0; round < ROUNDS; round++) {
-        const bool first = round == 0, last = round == ROUNDS - 1;
+    for (int round = ODD ? 1 : 0; round < ROUNDS; round++) {
+        const bool first = !ODD && round == 0, last = round == ROUNDS - 1;
         // which lane order this round runs in
         bool local;
         uint32_t c, j;
@@ -190,54 +241,24 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         if (ns_log > 0) tw1 = f29_load_raw(a.W + 12 * (size_t)e);
         F29 x0, x1, x2, x3;
         if (first) {
-            if (valid) {
-                const uint32_t* src = a.in + in_w * ((a.abl & 1 ? 0 : poly) + hi * a.inA + (a.abl & 1 ? lo & 7 : lo) * a.inB + c * a.inC);
-                const uint64_t s = (uint64_t)in_w * a.inS;
-                if (a.in_raw) {
-                    x0 = f29_load_raw(src + s * j);
-                    x1 = f29_load_raw(src + s * (j + Q));
-                    x2 = f29_load_raw(src + s * (j + 2 * Q));
-                    x3 = f29_load_raw(src + s * (j + 3 * Q));
-                } else {
-                    x0 = f29_from_fe(fe_load(src + s * j));
-                    x1 = f29_from_fe(fe_load(src + s * (j + Q)));
-                    x2 = f29_from_fe(fe_load(src + s * (j + 2 * Q)));
-                    x3 = f29_from_fe(fe_load(src + s * (j + 3 * Q)));
-                }
-            } else {
-#pragma unroll
-                for (int l = 0; l < 9; l++) x0.l[l] = x1.l[l] = x2.l[l] = x3.l[l] = 0;
-            }
+            const Quad29 q = load_inputs(c, j, valid);
+            x0 = q.a;
+            x1 = q.b;
+            x2 = q.c;
+            x3 = q.d;
         } else {
             x0 = lds_get29(lds, plane, at(c, j));
             x1 = lds_get29(lds, plane, at(c, j + Q));
             x2 = lds_get29(lds, plane, at(c, j + 2 * Q));
             x3 = lds_get29(lds, plane, at(c, j + 3 * Q));
         }
-        // Is the exchange that follows this round confined to each wavefront's own sub-image?
-        // (this round and the next both run in the local lane order, and Ns >= W keeps the low bits of j)
-        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !store_local && !(!a.store_cfast && LW == 0);
-        const uint32_t ns_next = ((LOGT & 1) && first) ? 1u : ns_log + 2;
-        const bool out_local = !last && local && ns_log >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
+        const bool out_local = exchange_is_local(round, local, ns_log, ns_log + 2);
         if (!first) {
             // inputs are in registers. If other wavefronts will overwrite them (cross-wave exchange)
             // every wavefront must have finished reading first; a wave-local exchange only needs the
             // compiler to keep this wavefront's own LDS order.
             if (out_local) __builtin_amdgcn_wave_barrier();
             else if (!last) __syncthreads();
-        }
-
-        if ((LOGT & 1) && first) {
-            // radix-2 level on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
-            F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
-            lds_put29(lds, plane, at(c, 2 * j), y0);
-            lds_put29(lds, plane, at(c, 2 * j + 1), y1);
-            lds_put29(lds, plane, at(c, 2 * (j + Q)), y2);
-            lds_put29(lds, plane, at(c, 2 * (j + Q) + 1), y3);
-            if (out_local) __builtin_amdgcn_wave_barrier();
-            else __syncthreads();
-            ns_log = 1;
-            continue;
         }
 
         if (ns_log > 0) {
