@@ -157,6 +157,29 @@ int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const vo
                                   size_t n, void* d_accept, void* d_digests, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Batch driver — verify_mimc_proof (reference src/lib.rs:99-197, with verify_low_degree_proof
+ * :31-97) over many serialized proofs (deserializer::from_bytes, src/deserializer.rs:142).
+ * ------------------------------------------------------------------------------------- */
+
+/*
+ * proofs: concatenated proof files; proof i is bytes [offsets[i], offsets[i+1]).
+ * inp, output: 8-limb field elements; round_constants: n_constants x 8 limbs; the modulus is p.
+ * accept[i] = 1 exactly when the reference returns true for proof i. status (may be NULL):
+ *   0 accepted                         1 parameter checks, reference returns false (:101-111)
+ *   2 malformed proof bytes            3 branch count / shape on which the reference panics
+ *   4 a recomputed Merkle root differs 5 low-degree check (:85)   6 transition (:181)
+ *   7 boundary (:187)                  8 linear combination (:190)
+ *   9 instance-size asserts (:50-51, :120-123: num_steps 8192, 64 round constants)
+ * All Merkle branches of a chunk of proofs (1,240 per proof) are hashed by the device in one call per
+ * (value size, witness count); parsing, index sampling (src/utils.rs:53-94) and the scalar field checks
+ * run on host threads (STARKHIP_HOST_THREADS, default min(cores, 16)). As in the reference, the final
+ * FRI "points" component is read and not verified (src/deserializer.rs:47-59, src/lib.rs:94).
+ */
+int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                            const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
+                            size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status);
+
+/* ---------------------------------------------------------------------------------------
  * Test and benchmark support (no counterpart in the reference).
  * ------------------------------------------------------------------------------------- */
 

@@ -1,0 +1,34 @@
+"""Host mirror of the batch driver: `verify_mimc_proof` (reference src/lib.rs:99) over many
+serialized proofs, Merkle branches hashed on the GPU."""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .fft import MODULUS, _limbs, _ptr
+
+STATUS = {0: "accepted", 1: "parameters rejected", 2: "malformed proof", 3: "branch shape", 4: "merkle mismatch",
+          5: "low-degree check", 6: "transition constraint", 7: "boundary constraint", 8: "linear combination",
+          9: "instance-size assert"}
+
+
+def verify_mimc_batch(proofs: Sequence[bytes], inp: int, num_steps: int, round_constants: Sequence[int], output: int,
+                      ctx: _lib.Context | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (accept, status): accept[i] == 1 exactly when the reference's verify_mimc_proof(inp,
+    num_steps, round_constants, output, proof_i, p) returns true; status[i] is a key of STATUS."""
+    ctx = ctx or _lib.default_context()
+    n = len(proofs)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(p) for p in proofs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(proofs), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    rc = np.ascontiguousarray(np.concatenate([_limbs(c % MODULUS) for c in round_constants]) if len(round_constants)
+                              else np.zeros(0, dtype=np.uint32))
+    accept = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.uint8)
+    i, o = _limbs(inp % MODULUS), _limbs(output % MODULUS)
+    ctx.check(ctx.lib.stark_mimc_verify_batch(ctx.handle, blob.ctypes.data if n else None, offsets.ctypes.data, n, _ptr(i),
+                                              num_steps, rc.ctypes.data if rc.size else None, len(round_constants), _ptr(o),
+                                              accept.ctypes.data if n else None, status.ctypes.data if n else None))
+    return accept, status

@@ -1,0 +1,491 @@
+// Batch driver: verify_mimc_proof (reference src/lib.rs:99-197) over many serialized proofs.
+//
+// Per chunk of proofs: (1) host threads parse the wire format (src/deserializer.rs:16-140), derive
+// the query indices (src/utils.rs:53-94) and flatten every Merkle branch of every proof into
+// structure-of-arrays buckets keyed by (value size, witness count); (2) one device call per bucket
+// recomputes all branch roots (the data-parallel part: 1,240 branches per proof); (3) host threads
+// run the scalar field checks of the protocol (FRI interpolation, transition / boundary / linear
+// combination constraints) on the proofs whose branches all matched.
+//
+// accept[i] = 1 exactly when the reference's verify_mimc_proof returns true for proof i. Where the
+// reference panics or returns false, accept[i] = 0 and status[i] names a check that fails (all
+// branches are hashed before the scalar checks, so it need not be the first one the reference
+// would reach).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <thread>
+#include <vector>
+
+#include "../../include/starkhip.h"
+#include "host_blake2s.hpp"
+#include "host_field.hpp"
+
+namespace starkhip {
+namespace batch {
+
+using hostfe::U256;
+
+// ---- scalar field helpers on canonical values ----
+static U256 fe_add(const U256& a, const U256& b) {
+    U256 r;
+    hostfe::u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (hostfe::u128)a.w[i] + b.w[i];
+        r.w[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c) hostfe::add_small(r, hostfe::FOLD);  // wrapped past 2^256: add 2^256 mod p
+    return hostfe::canon(r);
+}
+static U256 fe_neg(const U256& a) {
+    U256 z = {{0, 0, 0, 0}};
+    if (hostfe::eq(a, z)) return z;
+    U256 r;
+    hostfe::u128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        hostfe::u128 d = (hostfe::u128)hostfe::MODULUS.w[i] - a.w[i] - (uint64_t)borrow;
+        r.w[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+    return r;
+}
+static U256 fe_sub(const U256& a, const U256& b) { return fe_add(a, fe_neg(b)); }
+static U256 fe_mul(const U256& a, const U256& b) { return hostfe::mul(a, b); }
+// BigInt::from_bytes_be(Sign::Plus, 32 bytes) reduced mod p
+static U256 from_be(const uint8_t* b) {
+    U256 r;
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) w = (w << 8) | b[8 * (3 - i) + k];
+        r.w[i] = w;
+    }
+    return hostfe::canon(r);
+}
+// BigInt::from_bytes_be over a value of any length (values are 32 bytes in every proof seen;
+// longer ones are reduced the slow way)
+static U256 from_be_n(const uint8_t* b, size_t n) {
+    if (n == 32) return from_be(b);
+    U256 r = {{0, 0, 0, 0}};
+    const U256 k = hostfe::from_u64(256);
+    for (size_t i = 0; i < n; i++) r = fe_add(fe_mul(r, k), hostfe::from_u64(b[i]));
+    return r;
+}
+static bool is_zero(const U256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+
+// ---- wire format (src/deserializer.rs) ----
+struct BranchRef {
+    const uint8_t *value, *sibling, *wit;
+    uint32_t vs, w;
+};
+struct Layer {
+    const uint8_t* root2;
+    std::vector<BranchRef> col, poly;
+};
+struct Proof {
+    const uint8_t *merkle_root, *l_root;
+    std::vector<Layer> layers;
+    std::vector<BranchRef> merkle, lincomb;
+};
+struct Reader {
+    const uint8_t* p;
+    size_t len, off = 0;
+    bool ok = true;
+    const uint8_t* bytes(size_t n) {  // read_exact (deserializer.rs:9-14) panics past the end
+        if (!ok || n > len - off) {
+            ok = false;
+            return nullptr;
+        }
+        const uint8_t* r = p + off;
+        off += n;
+        return r;
+    }
+    uint32_t u32() {
+        const uint8_t* b = bytes(4);
+        return b ? (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24) : 0;
+    }
+};
+static bool parse_multiproof(Reader& r, std::vector<BranchRef>& out) {  // deserializer.rs:87-140
+    uint32_t n = r.u32();
+    if (!r.ok) return false;
+    out.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        BranchRef b;
+        b.vs = r.u32();
+        b.value = r.bytes(b.vs);
+        b.sibling = r.bytes(b.vs);
+        uint32_t wb = r.u32();
+        if (!r.ok || wb % 32 != 0) return false;  // assert at :117
+        b.w = wb / 32;
+        b.wit = r.bytes(wb);
+        if (!r.ok) return false;
+        out.push_back(b);
+    }
+    return true;
+}
+static bool parse_proof(const uint8_t* p, size_t len, Proof& out) {  // deserializer.rs:16-85
+    Reader r{p, len};
+    out.merkle_root = r.bytes(32);
+    out.l_root = r.bytes(32);
+    if (!r.ok) return false;
+    for (;;) {
+        uint32_t t = r.u32();
+        if (!r.ok) return false;
+        if (t == 1) {
+            Layer l;
+            l.root2 = r.bytes(32);
+            if (!r.ok || !parse_multiproof(r, l.col) || !parse_multiproof(r, l.poly)) return false;
+            out.layers.push_back(std::move(l));
+        } else if (t == 2) {
+            uint32_t nb = r.u32();
+            if (!r.ok || nb == 0 || nb % 32 != 0) return false;  // asserts at :53-54
+            r.bytes(nb);  // the points are read and dropped (:56-59)
+            if (!r.ok) return false;
+            break;
+        } else {
+            return false;  // panic at :61
+        }
+    }
+    return parse_multiproof(r, out.merkle) && parse_multiproof(r, out.lincomb);  // trailing bytes are tolerated
+}
+
+// src/utils.rs:53-94
+static std::vector<uint32_t> pseudorandom_indices(const uint8_t seed[32], size_t count, uint32_t modulus, uint32_t exclude) {
+    const uint32_t real_modulus = exclude ? (uint32_t)(modulus * (exclude - 1) / exclude) : modulus;
+    std::vector<uint8_t> hashes(seed, seed + 32);
+    while (hashes.size() < 4 * count) {
+        uint8_t d[32];
+        hostb2s::hash(hashes.data() + hashes.size() - 32, 32, d);
+        hashes.insert(hashes.end(), d, d + 32);
+    }
+    std::vector<uint32_t> out(count);
+    for (size_t j = 0; j < count; j++) {
+        const uint8_t* b = hashes.data() + 4 * j;
+        uint32_t x = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        out[j] = x % real_modulus;
+        if (exclude) out[j] = 1 + out[j] + out[j] / (exclude - 1);
+    }
+    return out;
+}
+
+enum Status : uint8_t {
+    ST_ACCEPT = 0,
+    ST_PARAMS = 1,        // verify_mimc_proof returns false (lib.rs:101-111)
+    ST_PARSE = 2,         // deserializer error / panic
+    ST_SHAPE = 3,         // branch count or branch shape on which MultiProof/ProofBranch::verify panics
+    ST_MERKLE = 4,        // recomputed root differs (assert at merkle_tree.rs:165)
+    ST_LOW_DEGREE = 5,    // lib.rs:85
+    ST_TRANSITION = 6,    // lib.rs:181
+    ST_BOUNDARY = 7,      // lib.rs:187
+    ST_LINEAR_COMB = 8,   // lib.rs:190
+    ST_INSTANCE = 9,      // the instance-size asserts at lib.rs:50-51,120-123
+};
+
+struct Params {
+    U256 inp, output;
+    uint64_t num_steps;
+    std::vector<U256> mini_poly;  // fft_inv(round_constants, val): computed once per call on the device
+    U256 g2, last_step;
+    uint64_t precision, skips, skips2;
+};
+
+// One multiproof's worth of queries: which branches, which indices, which root.
+struct Query {
+    const std::vector<BranchRef>* branches;
+    std::vector<uint32_t> indices;
+    const uint8_t* root;
+};
+
+struct Bucket {
+    uint32_t vs, w;
+    std::vector<const BranchRef*> br;
+    std::vector<uint32_t> idx, root_id, proof_id;
+};
+
+struct ProofWork {
+    Proof proof;
+    uint8_t status = ST_ACCEPT;
+    std::vector<Query> queries;                       // 2 per FRI layer + 2
+    std::vector<std::vector<uint32_t>> ys;            // per layer
+    std::vector<uint32_t> positions;
+};
+
+// Index derivation and the shape checks the reference makes before hashing.
+static void prepare(ProofWork& pw, const Params& P) {
+    const Proof& pr = pw.proof;
+    uint64_t rou_deg = P.precision;  // order of G2
+    const uint8_t* root = pr.l_root;
+    for (const Layer& l : pr.layers) {
+        std::vector<uint32_t> ys = pseudorandom_indices(l.root2, 40, (uint32_t)(rou_deg / 4), 8);
+        std::vector<uint32_t> pp;
+        for (uint32_t y : ys)
+            for (uint32_t i = 0; i < 4; i++) pp.push_back(y + (uint32_t)(rou_deg / 4) * i);
+        pw.queries.push_back(Query{&l.col, ys, l.root2});
+        pw.queries.push_back(Query{&l.poly, pp, root});
+        pw.ys.push_back(std::move(ys));
+        rou_deg /= 4;
+        root = l.root2;
+    }
+    pw.positions = pseudorandom_indices(pr.l_root, 80, (uint32_t)P.precision, 8);
+    std::vector<uint32_t> aug;
+    for (uint32_t p : pw.positions) {
+        aug.push_back(p);
+        aug.push_back((uint32_t)((p + P.skips) % P.precision));
+    }
+    pw.queries.push_back(Query{&pr.merkle, aug, pr.merkle_root});
+    pw.queries.push_back(Query{&pr.lincomb, pw.positions, pr.l_root});
+    for (const Query& q : pw.queries) {
+        if (q.branches->size() != q.indices.size()) {  // assert at merkle_tree.rs:28
+            pw.status = ST_SHAPE;
+            return;
+        }
+        for (const BranchRef& b : *q.branches)
+            if (b.w == 0 || b.w > 30 || b.vs < 32) {  // division by zero at :113, slice at :133, 2^w overflow
+                pw.status = ST_SHAPE;
+                return;
+            }
+    }
+    // the main trace leaves are read as three 32-byte fields (lib.rs:171-174)
+    for (size_t i = 0; i < pr.merkle.size(); i += 2)
+        if (pr.merkle[i].vs < 96) {
+            pw.status = ST_SHAPE;
+            return;
+        }
+}
+
+// utils.rs:196-244 for one group of four points; returns the cubic's coefficients, low to high
+static void interp_4(const U256 xs[4], const U256 ys[4], U256 out[4]) {
+    const U256 one = hostfe::from_u64(1);
+    for (int k = 0; k < 4; k++) out[k] = U256{{0, 0, 0, 0}};
+    for (int i = 0; i < 4; i++) {
+        U256 o[3];
+        for (int j = 0, k = 0; j < 4; j++)
+            if (j != i) o[k++] = xs[j];
+        U256 eq[4];
+        eq[0] = fe_neg(fe_mul(fe_mul(o[0], o[1]), o[2]));
+        eq[1] = fe_add(fe_add(fe_mul(o[0], o[1]), fe_mul(o[0], o[2])), fe_mul(o[1], o[2]));
+        eq[2] = fe_neg(fe_add(fe_add(o[0], o[1]), o[2]));
+        eq[3] = one;
+        const U256 x = xs[i], x2 = fe_mul(x, x), x3 = fe_mul(x2, x);
+        const U256 denom = fe_add(fe_add(eq[0], fe_mul(eq[1], x)), fe_add(fe_mul(eq[2], x2), x3));
+        const U256 f = fe_mul(ys[i], hostfe::inverse(denom));  // inv(0) = 0 as in utils.rs:144-146
+        for (int k = 0; k < 4; k++) out[k] = fe_add(out[k], fe_mul(eq[k], f));
+    }
+}
+
+// The scalar checks of lib.rs:31-97 and :161-192 on a proof whose branches all matched.
+static uint8_t field_checks(const ProofWork& pw, const Params& P) {
+    const Proof& pr = pw.proof;
+    U256 rou = P.g2;
+    uint64_t rou_deg = P.precision;
+    const uint8_t* root = pr.l_root;
+    for (size_t li = 0; li < pr.layers.size(); li++) {
+        const Layer& l = pr.layers[li];
+        const U256 quartic[4] = {hostfe::from_u64(1), hostfe::pow_u64(rou, rou_deg / 4), hostfe::pow_u64(rou, rou_deg / 2),
+                                 hostfe::pow_u64(rou, rou_deg * 3 / 4)};
+        const U256 special_x = from_be(root);
+        const U256 sx2 = fe_mul(special_x, special_x), sx3 = fe_mul(sx2, special_x);
+        for (size_t i = 0; i < pw.ys[li].size(); i++) {
+            const U256 x1 = hostfe::pow_u64(rou, pw.ys[li][i]);
+            U256 xs[4], rows[4], poly[4];
+            for (int j = 0; j < 4; j++) {
+                xs[j] = fe_mul(quartic[j], x1);
+                rows[j] = from_be_n(l.poly[i * 4 + j].value, l.poly[i * 4 + j].vs);
+            }
+            interp_4(xs, rows, poly);
+            const U256 got = fe_add(fe_add(poly[0], fe_mul(poly[1], special_x)), fe_add(fe_mul(poly[2], sx2), fe_mul(poly[3], sx3)));
+            if (!hostfe::eq(got, from_be_n(l.col[i].value, l.col[i].vs))) return ST_LOW_DEGREE;
+        }
+        rou = hostfe::pow_u64(rou, 4);
+        rou_deg /= 4;
+        root = l.root2;
+    }
+    U256 k[4];
+    for (int i = 0; i < 4; i++) {
+        uint8_t msg[33], d[32];
+        memcpy(msg, pr.merkle_root, 32);
+        msg[32] = (uint8_t)(i + 1);
+        hostb2s::hash(msg, 33, d);
+        k[i] = from_be(d);
+    }
+    const U256 one = hostfe::from_u64(1);
+    const U256 slope = fe_mul(fe_sub(P.output, P.inp), hostfe::inverse(fe_sub(P.last_step, one)));
+    for (size_t i = 0; i < pw.positions.size(); i++) {
+        const U256 x = hostfe::pow_u64(P.g2, pw.positions[i]);
+        const U256 x_steps = hostfe::pow_u64(x, P.num_steps);
+        const uint8_t *b1 = pr.merkle[2 * i].value, *b2 = pr.merkle[2 * i + 1].value;
+        const U256 l_of_x = from_be_n(pr.lincomb[i].value, pr.lincomb[i].vs);
+        const U256 p_of_x = from_be(b1), p_of_g1x = from_be(b2), d_of_x = from_be(b1 + 32), b_of_x = from_be(b1 + 64);
+        const U256 z = fe_mul(fe_sub(x_steps, one), hostfe::inverse(fe_sub(x, P.last_step)));
+        // k_of_x = constants_mini_polynomial(x^skips2)
+        const U256 xk = hostfe::pow_u64(x, P.skips2);
+        U256 kx = {{0, 0, 0, 0}}, pwx = one;
+        for (const U256& c : P.mini_poly) {
+            kx = fe_add(kx, fe_mul(pwx, c));
+            pwx = fe_mul(pwx, xk);
+        }
+        const U256 p3 = fe_mul(fe_mul(p_of_x, p_of_x), p_of_x);
+        if (!is_zero(fe_sub(fe_sub(fe_sub(p_of_g1x, p3), kx), fe_mul(z, d_of_x)))) return ST_TRANSITION;
+        const U256 interp = fe_add(P.inp, fe_mul(slope, fe_sub(x, one)));
+        const U256 zero2 = fe_mul(fe_sub(x, one), fe_sub(x, P.last_step));
+        if (!is_zero(fe_sub(fe_sub(p_of_x, fe_mul(b_of_x, zero2)), interp))) return ST_BOUNDARY;
+        U256 lc = fe_sub(l_of_x, d_of_x);
+        lc = fe_sub(lc, fe_mul(k[0], p_of_x));
+        lc = fe_sub(lc, fe_mul(fe_mul(k[1], p_of_x), x_steps));
+        lc = fe_sub(lc, fe_mul(k[2], b_of_x));
+        lc = fe_sub(lc, fe_mul(fe_mul(k[3], b_of_x), x_steps));
+        if (!is_zero(lc)) return ST_LINEAR_COMB;
+    }
+    return ST_ACCEPT;
+}
+
+template <class F>
+static void parallel_for(size_t n, unsigned threads, F f) {
+    if (threads <= 1 || n <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < std::min<size_t>(threads, n); t++)
+        pool.emplace_back([&] {
+            for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+        });
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace batch
+}  // namespace starkhip
+
+using namespace starkhip;
+using namespace starkhip::batch;
+
+extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                                       const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
+                                       size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
+    if (!inp || !output || (n_constants && !round_constants)) return STARK_ERR_INVALID;
+    for (size_t i = 0; i < n_proofs; i++)
+        if (offsets[i + 1] < offsets[i]) return STARK_ERR_INVALID;
+    auto set_all = [&](uint8_t st) {
+        for (size_t i = 0; i < n_proofs; i++) {
+            accept[i] = st == ST_ACCEPT;
+            if (status) status[i] = st;
+        }
+        return STARK_OK;
+    };
+    // parameter checks of lib.rs:101-111: the reference returns false
+    auto pow2 = [](uint64_t x) { return x && !(x & (x - 1)); };
+    if (num_steps > (1ull << 32) / 8 || !pow2(num_steps) || !pow2(n_constants) || n_constants > num_steps) return set_all(ST_PARAMS);
+    Params P;
+    P.inp = hostfe::canon(hostfe::from_limbs(inp));
+    P.output = hostfe::canon(hostfe::from_limbs(output));
+    P.num_steps = num_steps;
+    P.precision = num_steps * 8;
+    P.skips = 8;
+    P.skips2 = num_steps / n_constants;
+    // asserts at lib.rs:120 (num_steps), :123 (val, which fixes 64 round constants), :50 (rou_deg == 65536)
+    if (num_steps != 8192 || n_constants != 64) return set_all(ST_INSTANCE);
+    {
+        // G2 = 7^((p-1)/precision) (lib.rs:114); (p-1)/2^16 = p >> 16 because p-1 is a multiple of 2^32
+        U256 e = hostfe::MODULUS;
+        e.w[0] -= 1;
+        unsigned sh = 0;
+        while ((1ull << sh) < P.precision) sh++;
+        U256 q;
+        for (int i = 0; i < 4; i++) q.w[i] = (e.w[i] >> sh) | (i < 3 && sh ? e.w[i + 1] << (64 - sh) : 0);
+        P.g2 = hostfe::pow_u256(hostfe::from_u64(7), q);
+    }
+    P.last_step = hostfe::pow_u64(P.g2, (num_steps - 1) * P.skips);
+    {
+        // constants_mini_polynomial = fft_inv(round_constants, val) (lib.rs:118,125): on the device
+        const U256 val = hostfe::pow_u64(P.g2, 8 * P.skips2);
+        uint32_t root[8], mod[8];
+        hostfe::to_limbs(val, root);
+        hostfe::to_limbs(hostfe::MODULUS, mod);
+        std::vector<uint32_t> out(8 * n_constants);
+        int rc = stark_fft_inv(ctx, round_constants, n_constants, root, mod, out.data());
+        if (rc != STARK_OK) return rc;
+        for (size_t i = 0; i < n_constants; i++) P.mini_poly.push_back(hostfe::from_limbs(out.data() + 8 * i));
+    }
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* s = getenv("STARKHIP_HOST_THREADS")) threads = (unsigned)atoi(s);
+    threads = std::max(1u, std::min(threads, 16u));
+    size_t chunk_bytes = (size_t)1 << 30;
+    if (const char* s = getenv("STARKHIP_BATCH_MB")) chunk_bytes = (size_t)atoi(s) << 20;
+
+    for (size_t c0 = 0; c0 < n_proofs;) {
+        size_t c1 = c0 + 1;
+        while (c1 < n_proofs && offsets[c1 + 1] - offsets[c0] <= chunk_bytes) c1++;
+        const size_t m = c1 - c0;
+        std::vector<ProofWork> work(m);
+        parallel_for(m, threads, [&](size_t i) {
+            ProofWork& pw = work[i];
+            const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
+            if (!parse_proof(proofs + a, (size_t)(b - a), pw.proof)) {
+                pw.status = ST_PARSE;
+                return;
+            }
+            prepare(pw, P);
+        });
+        // bucket every branch of the chunk by shape; roots are deduplicated per proof
+        std::map<std::pair<uint32_t, uint32_t>, Bucket> buckets;
+        std::vector<uint8_t> roots;
+        for (size_t i = 0; i < m; i++) {
+            ProofWork& pw = work[i];
+            if (pw.status != ST_ACCEPT) continue;
+            for (const Query& q : pw.queries) {
+                const uint32_t rid = (uint32_t)(roots.size() / 32);
+                roots.insert(roots.end(), q.root, q.root + 32);
+                for (size_t k = 0; k < q.branches->size(); k++) {
+                    const BranchRef& b = (*q.branches)[k];
+                    Bucket& bk = buckets[{b.vs, b.w}];
+                    bk.vs = b.vs;
+                    bk.w = b.w;
+                    bk.br.push_back(&b);
+                    bk.idx.push_back(q.indices[k]);
+                    bk.root_id.push_back(rid);
+                    bk.proof_id.push_back((uint32_t)i);
+                }
+            }
+        }
+        std::vector<std::atomic<uint8_t>> merkle_bad(m);
+        for (auto& x : merkle_bad) x.store(0);
+        for (auto& kv : buckets) {
+            Bucket& bk = kv.second;
+            const size_t n = bk.br.size();
+            std::vector<uint8_t> values(n * bk.vs), sibs(n * bk.vs), wit((size_t)bk.w * n * 32), acc(n);
+            parallel_for((n + 4095) / 4096, threads, [&](size_t blk) {
+                const size_t lo = blk * 4096, hi = std::min(n, lo + 4096);
+                for (size_t k = lo; k < hi; k++) {
+                    const BranchRef& b = *bk.br[k];
+                    memcpy(&values[k * bk.vs], b.value, bk.vs);
+                    memcpy(&sibs[k * bk.vs], b.sibling, bk.vs);
+                    for (uint32_t l = 0; l < bk.w; l++) memcpy(&wit[((size_t)l * n + k) * 32], b.wit + 32 * l, 32);
+                }
+            });
+            int rc = stark_merkle_verify_batch(ctx, values.data(), sibs.data(), bk.vs, wit.data(), bk.w, bk.idx.data(),
+                                               roots.data(), (uint32_t)(roots.size() / 32), bk.root_id.data(), n, acc.data(),
+                                               nullptr);
+            if (rc != STARK_OK) return rc;
+            for (size_t k = 0; k < n; k++)
+                if (!acc[k]) merkle_bad[bk.proof_id[k]].store(1);
+        }
+        parallel_for(m, threads, [&](size_t i) {
+            ProofWork& pw = work[i];
+            if (pw.status == ST_ACCEPT && merkle_bad[i].load()) pw.status = ST_MERKLE;
+            if (pw.status == ST_ACCEPT) pw.status = field_checks(pw, P);
+        });
+        for (size_t i = 0; i < m; i++) {
+            accept[c0 + i] = work[i].status == ST_ACCEPT;
+            if (status) status[c0 + i] = work[i].status;
+        }
+        c0 = c1;
+    }
+    return STARK_OK;
+}

@@ -1,0 +1,113 @@
+"""Batch driver (stark_mimc_verify_batch): accept bits against the Python restatement of the
+reference's verify_mimc_proof (tests/ref_verifier.py with the oracle plugged in, itself pinned by
+proof.bin) on the reference's bundled proof and corrupted copies of it."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle
+import proofio
+import ref_verifier as rv
+from test_oracle import _oracle_hooks
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_accepts(blob, inp, steps, consts, output):
+    """What the reference does with these bytes: True, or False for both `return false` and a panic."""
+    try:
+        proof, _ = proofio.parse_proof(blob)
+        return bool(rv.verify_mimc_proof(inp, steps, consts, output, proof, _oracle_hooks()))
+    except (AssertionError, ValueError, IndexError, struct.error, ZeroDivisionError):
+        return False
+
+
+def _variants(good: bytes):
+    proof, _ = proofio.parse_proof(good)
+    v = {"good": good}
+    # offsets of interesting bytes, found by searching the serialized fields
+    def off_of(field: bytes, start=0):
+        o = good.find(field, start)
+        assert o >= 0
+        return o
+    def flip(o, mask=0x01):
+        b = bytearray(good)
+        b[o] ^= mask
+        return bytes(b)
+    v["witness_bit"] = flip(off_of(proof.fri_layers[2].poly_branches.branches[17].witnesses[3]) + 5, 0x10)
+    v["column_value_bit"] = flip(off_of(proof.fri_layers[0].column_branches.branches[0].value) + 31)
+    v["trace_value_bit"] = flip(off_of(proof.merkle_branches.branches[3].value) + 40)
+    v["lincomb_sibling_bit"] = flip(off_of(proof.linear_comb_branches.branches[79].sibling_value), 0x80)
+    v["root2_bit"] = flip(off_of(proof.fri_layers[4].root2) + 1)
+    v["merkle_root_bit"] = flip(0)
+    v["points_bit"] = flip(off_of(proof.points) + 100)          # never verified by the reference: still accepted
+    v["truncated"] = good[:len(good) // 2]
+    v["bad_element_type"] = good[:64] + struct.pack("<I", 7) + good[68:]
+    v["trailing_bytes"] = good + b"\x00" * 13                    # tolerated by the reference's parser
+    v["empty"] = b""
+    # a branch that loses its last witness: shape change -> different tree depth -> mismatch
+    return v
+
+
+def test_batch_accept_bits_match_reference_restatement(proof_bytes):
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    variants = _variants(proof_bytes)
+    names = list(variants)
+    expect = {k: _ref_accepts(variants[k], 3, 8192, consts, output) for k in names}
+    assert expect["good"] and expect["points_bit"] and expect["trailing_bytes"]
+    assert not any(expect[k] for k in names if k not in ("good", "points_bit", "trailing_bytes"))
+    order = [names[(7 * i) % len(names)] for i in range(60)]
+    accept, status = batch.verify_mimc_batch([variants[k] for k in order], 3, 8192, consts, output)
+    assert [bool(a) for a in accept] == [expect[k] for k in order]
+    by = {k: int(status[order.index(k)]) for k in names}
+    assert by["good"] == 0 and by["points_bit"] == 0 and by["trailing_bytes"] == 0
+    assert by["truncated"] == 2 and by["bad_element_type"] == 2 and by["empty"] == 2
+    for k in ("witness_bit", "column_value_bit", "trace_value_bit", "lincomb_sibling_bit", "root2_bit", "merkle_root_bit"):
+        assert by[k] == 4, (k, by[k])
+
+
+def test_batch_public_parameters(proof_bytes):
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    good = [proof_bytes, proof_bytes]
+    # wrong output / input: boundary constraint (src/lib.rs:187)
+    for inp, out in ((3, output + 1), (4, output)):
+        a, s = batch.verify_mimc_batch(good, inp, 8192, consts, out)
+        assert list(a) == [0, 0] and list(s) == [7, 7]
+        assert not _ref_accepts(proof_bytes, inp, 8192, consts, out)
+    # wrong round constant: transition constraint (src/lib.rs:181)
+    bad = list(consts)
+    bad[5] += 1
+    a, s = batch.verify_mimc_batch(good, 3, 8192, bad, output)
+    assert list(a) == [0, 0] and list(s) == [6, 6]
+    assert not _ref_accepts(proof_bytes, 3, 8192, bad, output)
+    # parameter checks that make the reference return false (src/lib.rs:101-111)
+    for steps, cs in ((8191, consts), (8192, consts[:63]), (2**30, consts), (32, consts)):
+        a, s = batch.verify_mimc_batch(good, 3, steps, cs, output)
+        assert list(a) == [0, 0] and list(s) == [1, 1], (steps, len(cs))
+    # other instance sizes trip the reference's asserts (src/lib.rs:120-123)
+    a, s = batch.verify_mimc_batch(good, 3, 4096, consts, output)
+    assert list(a) == [0, 0] and list(s) == [9, 9]
+    a, s = batch.verify_mimc_batch(good, 3, 8192, consts[:32], output)
+    assert list(a) == [0, 0] and list(s) == [9, 9]
+    # empty batch
+    a, s = batch.verify_mimc_batch([], 3, 8192, consts, output)
+    assert a.size == 0
+
+
+def test_batch_chunking_and_threads_give_the_same_answer(proof_bytes, monkeypatch):
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    v = _variants(proof_bytes)
+    blobs = [v["good"], v["witness_bit"], v["good"], v["truncated"], v["good"], v["trace_value_bit"], v["points_bit"]] * 3
+    ref, _ = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert list(ref) == [1, 0, 1, 0, 1, 0, 1] * 3
+    monkeypatch.setenv("STARKHIP_BATCH_MB", "1")   # one or two proofs per chunk
+    monkeypatch.setenv("STARKHIP_HOST_THREADS", "1")
+    a, _ = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref)
