@@ -4,6 +4,7 @@
 //   fft::fft_inv(v, root_of_unity, modulus) -> Vec<BigInt>        reference src/fft.rs:64
 //   ProofBranch { witnesses, sibling_value, value }::verify        reference src/merkle_tree.rs:11-15,119
 //   MultiProof { branches, root }::verify(indices, rt)             reference src/merkle_tree.rs:18-21,25
+//   verify_mimc_proof(inp, num_steps, round_constants, output, proof, modulus), batched   reference src/lib.rs:99
 // A BigInt is a U256 here (32 bytes, little-endian limbs, any value; results are canonical).
 // Error behaviour: where the reference panics, these throw std::runtime_error (a Merkle
 // mismatch throws MerkleMismatch unless `strict` is false, then the result is std::nullopt —
@@ -135,4 +136,25 @@ inline std::optional<Value> ProofBranch::verify(Context& c, const MerkleDigest& 
 }
 
 }  // namespace merkle_tree
+
+// verify_mimc_proof(inp, num_steps, round_constants, output, proof, modulus) (reference src/lib.rs:99) over a
+// batch of serialized proofs (each what deserializer::from_bytes reads, src/deserializer.rs:142). Returns one
+// flag per proof: true exactly when the reference returns true; false where it returns false or panics.
+// `status`, if given, receives the reason per proof (codes in include/starkhip.h).
+inline std::vector<bool> verify_mimc_proofs(Context& c, const U256& inp, size_t num_steps, const std::vector<U256>& round_constants,
+                                            const U256& output, const std::vector<std::vector<uint8_t>>& proofs,
+                                            std::vector<uint8_t>* status = nullptr) {
+    std::vector<uint64_t> offsets(proofs.size() + 1, 0);
+    for (size_t i = 0; i < proofs.size(); i++) offsets[i + 1] = offsets[i] + proofs[i].size();
+    std::vector<uint8_t> blob(offsets.back());
+    for (size_t i = 0; i < proofs.size(); i++)
+        if (!proofs[i].empty()) std::memcpy(&blob[offsets[i]], proofs[i].data(), proofs[i].size());
+    std::vector<uint8_t> accept(proofs.size()), st(proofs.size());
+    c.check(stark_mimc_verify_batch(c.get(), blob.data(), offsets.data(), proofs.size(), inp.data(), num_steps,
+                                    round_constants.empty() ? nullptr : round_constants[0].data(), round_constants.size(),
+                                    output.data(), accept.data(), st.data()));
+    if (status) *status = st;
+    return std::vector<bool>(accept.begin(), accept.end());
+}
+
 }  // namespace starkhost

@@ -29,7 +29,17 @@ static U256 from_be_hex(const char* s) {  // 64 hex digits, big-endian
     return r;
 }
 
-int main() {
+static std::vector<uint8_t> read_file(const char* path) {
+    std::vector<uint8_t> b;
+    if (FILE* f = fopen(path, "rb")) {
+        uint8_t buf[65536];
+        for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) b.insert(b.end(), buf, buf + n);
+        fclose(f);
+    }
+    return b;
+}
+
+int main(int argc, char** argv) {
     Context ctx(0);
     const char* d[14] = {"ba5ba7ea7c0fe5ea738a8d207f0797dbb0658bdceeb6be707e5e912f0f7b2728",
                          "e845c8789914f8e0b5d11bd7f90471820cfd568e735343bf4661da8b1dda0648",
@@ -75,6 +85,20 @@ int main() {
     threw = false;
     try { fft::fft_inv(ctx, std::vector<U256>(consts.begin(), consts.begin() + 32), val, modulus()); } catch (const std::runtime_error&) { threw = true; }
     if (!threw) { printf("FAIL: wrong-order root accepted\n"); return 1; }
+    if (argc > 1) {
+        // verify_mimc_proof(3, 8192, constants, mimc(3, 8192, constants), proof, p) as reference src/main.rs:204-222
+        // runs it, over a batch: the bundled proof, a copy with one witness bit flipped, the proof again
+        std::vector<uint8_t> good = read_file(argv[1]);
+        if (good.empty()) { printf("FAIL: cannot read %s\n", argv[1]); return 1; }
+        std::vector<uint8_t> bad = good;
+        bad[good.size() / 3] ^= 0x20;
+        U256 inp{3, 0, 0, 0, 0, 0, 0, 0};
+        U256 out = from_be_hex("d2874ff35f56a2f7f5e0cfc8c4e6ae570f3636219c6a3bc8810deec3361ad858");
+        std::vector<uint8_t> status;
+        std::vector<bool> acc = verify_mimc_proofs(ctx, inp, 8192, consts, out, {good, bad, good}, &status);
+        if (!(acc[0] && !acc[1] && acc[2])) { printf("FAIL: batch accept bits %d %d %d\n", (int)acc[0], (int)acc[1], (int)acc[2]); return 1; }
+        if (status[0] != 0 || status[1] == 0) { printf("FAIL: batch status\n"); return 1; }
+    }
     printf("host mirror ok\n");
     return 0;
 }

@@ -13,9 +13,12 @@
 // would reach).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <map>
 #include <thread>
@@ -24,6 +27,7 @@
 #include "../../include/starkhip.h"
 #include "host_blake2s.hpp"
 #include "host_field.hpp"
+#include "internal.hpp"
 
 namespace starkhip {
 namespace batch {
@@ -212,6 +216,7 @@ struct ProofWork {
     std::vector<Query> queries;                       // 2 per FRI layer + 2
     std::vector<std::vector<uint32_t>> ys;            // per layer
     std::vector<uint32_t> positions;
+    bool plain_values = true;  // every value the scalar checks read as one number is 32 bytes (device lanes copy 32)
 };
 
 // Index derivation and the shape checks the reference makes before hashing.
@@ -249,6 +254,11 @@ static void prepare(ProofWork& pw, const Params& P) {
                 return;
             }
     }
+    for (const Layer& l : pr.layers) {
+        for (const BranchRef& b : l.col) pw.plain_values &= b.vs == 32;
+        for (const BranchRef& b : l.poly) pw.plain_values &= b.vs == 32;
+    }
+    for (const BranchRef& b : pr.lincomb) pw.plain_values &= b.vs == 32;
     // the main trace leaves are read as three 32-byte fields (lib.rs:171-174)
     for (size_t i = 0; i < pr.merkle.size(); i += 2)
         if (pr.merkle[i].vs < 96) {
@@ -358,6 +368,91 @@ static void parallel_for(size_t n, unsigned threads, F f) {
     for (auto& th : pool) th.join();
 }
 
+// The same checks on the device: one lane per (proof, layer, sample) and per (proof, position).
+static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, const Params& P, const CheckParams& CP,
+                               const uint32_t* d_mini, unsigned threads) {
+    const size_t m = work.size();
+    std::vector<size_t> fri_off(m + 1, 0), con_off(m + 1, 0);
+    for (size_t i = 0; i < m; i++) {
+        size_t f = 0, c = 0;
+        if (work[i].status == ST_ACCEPT && !work[i].plain_values) work[i].status = field_checks(work[i], P);  // rare: host path
+        else if (work[i].status == ST_ACCEPT) {
+            for (auto& ys : work[i].ys) f += ys.size();
+            c = work[i].positions.size();
+        }
+        fri_off[i + 1] = fri_off[i] + f;
+        con_off[i + 1] = con_off[i] + c;
+    }
+    const size_t nf = fri_off[m], nc = con_off[m];
+    if (nf + nc == 0) return STARK_OK;
+    std::vector<FriLane> fri(nf);
+    std::vector<ConstraintLane> con(nc);
+    std::vector<uint8_t> kk(128 * m, 0);
+    parallel_for(m, threads, [&](size_t i) {
+        ProofWork& pw = work[i];
+        if (pw.status != ST_ACCEPT || !pw.plain_values) return;
+        const Proof& pr = pw.proof;
+        size_t o = fri_off[i];
+        const uint8_t* root = pr.l_root;
+        for (size_t li = 0; li < pr.layers.size(); li++) {
+            const Layer& l = pr.layers[li];
+            for (size_t k = 0; k < pw.ys[li].size(); k++, o++) {
+                FriLane& L = fri[o];
+                for (int j = 0; j < 4; j++) memcpy(L.rows[j], l.poly[k * 4 + j].value, 32);
+                memcpy(L.col, l.col[k].value, 32);
+                memcpy(L.special, root, 32);
+                L.y = pw.ys[li][k];
+                L.layer = (uint32_t)li;
+                L.pad[0] = L.pad[1] = 0;
+            }
+            root = l.root2;
+        }
+        for (int k = 0; k < 4; k++) {
+            uint8_t msg[33];
+            memcpy(msg, pr.merkle_root, 32);
+            msg[32] = (uint8_t)(k + 1);
+            hostb2s::hash(msg, 33, &kk[128 * i + 32 * k]);
+        }
+        o = con_off[i];
+        for (size_t k = 0; k < pw.positions.size(); k++, o++) {
+            ConstraintLane& L = con[o];
+            memcpy(L.b1, pr.merkle[2 * k].value, 96);
+            memcpy(L.pg, pr.merkle[2 * k + 1].value, 32);
+            memcpy(L.l, pr.lincomb[k].value, 32);
+            L.pos = pw.positions[k];
+            L.proof = (uint32_t)i;
+            L.pad[0] = L.pad[1] = 0;
+        }
+    });
+    const size_t bytes_f = nf * sizeof(FriLane), bytes_c = nc * sizeof(ConstraintLane), bytes_k = kk.size();
+    auto up16 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_c = up16(bytes_f), o_k = o_c + up16(bytes_c), o_s = o_k + up16(bytes_k), total = o_s + up16(nf + nc);
+    uint8_t* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return STARK_ERR_NOMEM;
+    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+    std::vector<uint8_t> res(nf + nc);
+    e = hipMemcpyAsync(d, fri.data(), bytes_f, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_c, con.data(), bytes_c, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_k, kk.data(), bytes_k, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_fri_check((const FriLane*)d, nf, CP, d + o_s, st);
+    if (e == hipSuccess)
+        e = launch_constraint_check((const ConstraintLane*)(d + o_c), nc, CP, d + o_k, d_mini, d + o_s + nf, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(res.data(), d + o_s, nf + nc, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return STARK_ERR_HIP;
+    for (size_t i = 0; i < m; i++) {
+        if (work[i].status != ST_ACCEPT || !work[i].plain_values) continue;
+        uint8_t stt = ST_ACCEPT;
+        for (size_t k = fri_off[i]; k < fri_off[i + 1] && !stt; k++) stt = res[k];
+        for (size_t k = con_off[i]; k < con_off[i + 1] && !stt; k++) stt = res[nf + k];
+        work[i].status = stt;
+    }
+    (void)P;
+    return STARK_OK;
+}
+
 }  // namespace batch
 }  // namespace starkhip
 
@@ -413,17 +508,53 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         if (rc != STARK_OK) return rc;
         for (size_t i = 0; i < n_constants; i++) P.mini_poly.push_back(hostfe::from_limbs(out.data() + 8 * i));
     }
+    // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host
+    const char* fenv = getenv("STARKHIP_BATCH_FIELD");
+    const bool field_on_host = fenv && strcmp(fenv, "host") == 0;
+    // diagnostic: let the scalar checks decide even when a branch mismatched (compares the host and device
+    // versions of those checks on corrupted values); never set in production
+    const bool skip_merkle = getenv("STARKHIP_BATCH_IGNORE_MERKLE") != nullptr;
+    CheckParams CP;
+    uint32_t* d_mini = nullptr;
+    {
+        const U256 one = hostfe::from_u64(1);
+        const U256 slope = fe_mul(fe_sub(P.output, P.inp), hostfe::inverse(fe_sub(P.last_step, one)));
+        hostfe::to_limbs(P.g2, CP.g2);
+        hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
+        hostfe::to_limbs(P.last_step, CP.last_step);
+        hostfe::to_limbs(P.inp, CP.inp);
+        hostfe::to_limbs(slope, CP.slope);
+        CP.precision = (uint32_t)P.precision;
+        CP.log_steps = CP.log_skips2 = 0;
+        while ((1ull << CP.log_steps) < P.num_steps) CP.log_steps++;
+        while ((1ull << CP.log_skips2) < P.skips2) CP.log_skips2++;
+        CP.n_coeffs = (uint32_t)P.mini_poly.size();
+        if (!field_on_host) {
+            std::vector<uint32_t> mp(8 * P.mini_poly.size());
+            for (size_t i = 0; i < P.mini_poly.size(); i++) hostfe::to_limbs(hostfe::canon(P.mini_poly[i]), &mp[8 * i]);
+            if (hipMalloc((void**)&d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
+            if (hipMemcpy(d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d_mini);
+                return STARK_ERR_HIP;
+            }
+        }
+    }
     unsigned threads = std::thread::hardware_concurrency();
     if (const char* s = getenv("STARKHIP_HOST_THREADS")) threads = (unsigned)atoi(s);
     threads = std::max(1u, std::min(threads, 16u));
     size_t chunk_bytes = (size_t)1 << 30;
     if (const char* s = getenv("STARKHIP_BATCH_MB")) chunk_bytes = (size_t)atoi(s) << 20;
 
+    // STARKHIP_BATCH_TIMING=1 prints per-stage wall time to stderr
+    const bool timing = getenv("STARKHIP_BATCH_TIMING") != nullptr;
+    double t_parse = 0, t_bucket = 0, t_flatten = 0, t_merkle = 0, t_field = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t c0 = 0; c0 < n_proofs;) {
         size_t c1 = c0 + 1;
         while (c1 < n_proofs && offsets[c1 + 1] - offsets[c0] <= chunk_bytes) c1++;
         const size_t m = c1 - c0;
         std::vector<ProofWork> work(m);
+        double t0 = now();
         parallel_for(m, threads, [&](size_t i) {
             ProofWork& pw = work[i];
             const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
@@ -433,6 +564,8 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
             }
             prepare(pw, P);
         });
+        t_parse += now() - t0;
+        t0 = now();
         // bucket every branch of the chunk by shape; roots are deduplicated per proof
         std::map<std::pair<uint32_t, uint32_t>, Bucket> buckets;
         std::vector<uint8_t> roots;
@@ -454,11 +587,13 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
                 }
             }
         }
+        t_bucket += now() - t0;
         std::vector<std::atomic<uint8_t>> merkle_bad(m);
         for (auto& x : merkle_bad) x.store(0);
         for (auto& kv : buckets) {
             Bucket& bk = kv.second;
             const size_t n = bk.br.size();
+            t0 = now();
             std::vector<uint8_t> values(n * bk.vs), sibs(n * bk.vs), wit((size_t)bk.w * n * 32), acc(n);
             parallel_for((n + 4095) / 4096, threads, [&](size_t blk) {
                 const size_t lo = blk * 4096, hi = std::min(n, lo + 4096);
@@ -469,23 +604,44 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
                     for (uint32_t l = 0; l < bk.w; l++) memcpy(&wit[((size_t)l * n + k) * 32], b.wit + 32 * l, 32);
                 }
             });
+            t_flatten += now() - t0;
+            t0 = now();
             int rc = stark_merkle_verify_batch(ctx, values.data(), sibs.data(), bk.vs, wit.data(), bk.w, bk.idx.data(),
                                                roots.data(), (uint32_t)(roots.size() / 32), bk.root_id.data(), n, acc.data(),
                                                nullptr);
-            if (rc != STARK_OK) return rc;
+            if (rc != STARK_OK) {
+                (void)hipFree(d_mini);
+                return rc;
+            }
             for (size_t k = 0; k < n; k++)
                 if (!acc[k]) merkle_bad[bk.proof_id[k]].store(1);
+            t_merkle += now() - t0;
         }
-        parallel_for(m, threads, [&](size_t i) {
-            ProofWork& pw = work[i];
-            if (pw.status == ST_ACCEPT && merkle_bad[i].load()) pw.status = ST_MERKLE;
-            if (pw.status == ST_ACCEPT) pw.status = field_checks(pw, P);
-        });
+        t0 = now();
+        for (size_t i = 0; i < m; i++)
+            if (work[i].status == ST_ACCEPT && merkle_bad[i].load() && !skip_merkle) work[i].status = ST_MERKLE;
+        if (field_on_host) {
+            parallel_for(m, threads, [&](size_t i) {
+                ProofWork& pw = work[i];
+                if (pw.status == ST_ACCEPT) pw.status = field_checks(pw, P);
+            });
+        } else {
+            int rc = device_field_checks(ctx, work, P, CP, d_mini, threads);
+            if (rc != STARK_OK) {
+                (void)hipFree(d_mini);
+                return rc;
+            }
+        }
+        t_field += now() - t0;
         for (size_t i = 0; i < m; i++) {
             accept[c0 + i] = work[i].status == ST_ACCEPT;
             if (status) status[c0 + i] = work[i].status;
         }
         c0 = c1;
     }
+    (void)hipFree(d_mini);
+    if (timing)
+        fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
+                n_proofs, t_parse, t_bucket, t_flatten, t_merkle, t_field);
     return STARK_OK;
 }

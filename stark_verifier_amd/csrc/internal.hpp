@@ -61,6 +61,33 @@ hipError_t launch_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_
 // synthetic canonical field elements from SplitMix64(seed), 4 draws per element
 hipError_t launch_fill_random_field(uint32_t* out, size_t n, uint64_t seed, hipStream_t stream);
 
+// ---- protocol-layer field checks of the batch driver (checks.hip) ----
+// One sampled position of one FRI layer (reference src/lib.rs:73-86); byte fields are the proof's own
+// big-endian values, copied as they are.
+struct alignas(16) FriLane {
+    uint8_t rows[4][32];  // poly_values[i*4 + j]
+    uint8_t col[32];      // column_values[i]
+    uint8_t special[32];  // the previous layer's root (special_x)
+    uint32_t y, layer;
+    uint32_t pad[2];
+};
+// One spot-check position of verify_mimc_proof (reference src/lib.rs:163-192)
+struct alignas(16) ConstraintLane {
+    uint8_t b1[96];  // P(x) | D(x) | B(x)
+    uint8_t pg[32];  // P(g1 x)
+    uint8_t l[32];   // L(x)
+    uint32_t pos, proof;
+    uint32_t pad[2];
+};
+struct CheckParams {
+    uint32_t g2[8], q4[8], last_step[8], inp[8], slope[8];  // canonical limbs
+    uint32_t precision, log_steps, log_skips2, n_coeffs;
+};
+hipError_t launch_fri_check(const FriLane* lanes, size_t n, const CheckParams& P, uint8_t* status, hipStream_t stream);
+// kk: per proof 4 x 32 bytes BLAKE2s(merkle_root || {1,2,3,4}); mini_poly: n_coeffs x 8 canonical limbs
+hipError_t launch_constraint_check(const ConstraintLane* lanes, size_t n, const CheckParams& P, const uint8_t* kk,
+                                   const uint32_t* mini_poly, uint8_t* status, hipStream_t stream);
+
 // sharded-transform helpers (shard.hip)
 hipError_t launch_twiddle_mul(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0,
                               uint32_t log_order, uint32_t lo_bits, const uint32_t* lo, const uint32_t* hi,

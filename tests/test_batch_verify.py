@@ -111,3 +111,38 @@ def test_batch_chunking_and_threads_give_the_same_answer(proof_bytes, monkeypatc
     monkeypatch.setenv("STARKHIP_HOST_THREADS", "1")
     a, _ = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
     assert np.array_equal(a, ref)
+
+
+def test_device_field_checks_agree_with_host_checks(proof_bytes, monkeypatch):
+    """The scalar checks run on the device by default and on host threads with STARKHIP_BATCH_FIELD=host.
+    With Merkle mismatches ignored (diagnostic switch) they alone decide, so corrupted values exercise every
+    check: both versions must report the same status for every proof."""
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    proof, _ = proofio.parse_proof(proof_bytes)
+    rng = np.random.default_rng(3)
+    blobs = [proof_bytes]
+    fields = []
+    for l in proof.fri_layers:
+        fields += [b.value for b in l.column_branches.branches] + [b.value for b in l.poly_branches.branches]
+    fields += [b.value for b in proof.merkle_branches.branches] + [b.value for b in proof.linear_comb_branches.branches]
+    for _ in range(150):
+        f = fields[int(rng.integers(len(fields)))]
+        o = proof_bytes.find(f)
+        b = bytearray(proof_bytes)
+        b[o + int(rng.integers(len(f)))] ^= 1 << int(rng.integers(8))
+        blobs.append(bytes(b))
+    monkeypatch.setenv("STARKHIP_BATCH_IGNORE_MERKLE", "1")
+    a_dev, s_dev = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    monkeypatch.setenv("STARKHIP_BATCH_FIELD", "host")
+    a_host, s_host = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(s_dev, s_host), list(zip(s_dev, s_host))
+    assert s_dev[0] == 0 and set(s_dev[1:].tolist()) >= {5, 6, 7, 8} or set(s_dev[1:].tolist()) >= {5, 6}
+    # values that only sit in a sibling slot of another query are not read by the scalar checks; everything
+    # that is read must fail some check
+    assert (s_dev[1:] != 0).sum() > 100
+    monkeypatch.delenv("STARKHIP_BATCH_IGNORE_MERKLE")
+    monkeypatch.delenv("STARKHIP_BATCH_FIELD")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert a[0] == 1 and not a[1:].any() and set(s[1:].tolist()) == {4}

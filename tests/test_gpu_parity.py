@@ -340,5 +340,6 @@ def test_cpp_host_mirror_binary(sv):
     if not os.path.exists(exe):
         pytest.fail("host/test_host is not built (make -C stark_verifier_amd/csrc host)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "proof.bin")], capture_output=True, text=True,
+                       timeout=120, env=env)
     assert r.returncode == 0 and "host mirror ok" in r.stdout, r.stdout + r.stderr
