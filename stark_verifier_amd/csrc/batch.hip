@@ -21,6 +21,7 @@
 #include <chrono>
 #include <atomic>
 #include <map>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -459,9 +460,15 @@ static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, con
 using namespace starkhip;
 using namespace starkhip::batch;
 
+// Nothing may unwind across the C ABI: every entry point is a function-try-block.
+#define STARK_CATCH                                              \
+    catch (const std::bad_alloc&) { return STARK_ERR_NOMEM; }    \
+    catch (...) { return STARK_ERR_HIP; }
+
+
 extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
                                        const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
-                                       size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) {
+                                       size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
     if (!inp || !output || (n_constants && !round_constants)) return STARK_ERR_INVALID;
@@ -644,4 +651,4 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
                 n_proofs, t_parse, t_bucket, t_flatten, t_merkle, t_field);
     return STARK_OK;
-}
+} STARK_CATCH

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,8 @@ struct NttPlan {
     bool limb29 = true;  // passes run on the 29-bit-limb kernels (intermediates are 48 bytes/element)
     uint32_t scale[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     int has_scale = 0;
+    size_t table_bytes = 0;   // device memory held by `tables`
+    uint64_t last_use = 0;    // for least-recently-used eviction
 };
 
 }  // namespace
@@ -50,6 +53,8 @@ struct stark_ctx {
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
     size_t chunk_bytes = (size_t)512 << 20;  // input bytes transformed per group of pass launches
+    size_t table_budget = (size_t)8 << 30;   // twiddle tables kept across calls (STARKHIP_TABLE_MB)
+    uint64_t use_counter = 0;
 };
 
 namespace {
@@ -145,6 +150,7 @@ int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, ui
         return fail(ctx, STARK_ERR_NOMEM, "twiddle table of %zu bytes: %s", count * 32, hipGetErrorString(e));
     }
     plan->tables.push_back(d_tab);
+    plan->table_bytes += count * (unpack ? 48 : 32);
     uint32_t sc[8];
     hostfe::to_limbs(scale, sc);
     e = hipMemcpyAsync(d_pw, pw, sizeof pw, hipMemcpyHostToDevice, ctx->stream);
@@ -170,6 +176,7 @@ int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, ui
 void free_plan(NttPlan* p) {
     for (void* t : p->tables) (void)hipFree(t);
     p->tables.clear();
+    p->table_bytes = 0;
 }
 
 // `root` has order exactly 2^log_n (checked by the caller).
@@ -358,13 +365,38 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
     return STARK_OK;
 }
 
+// Cached plans are kept until their tables exceed the budget; then the least recently used ones go.
+// Their tables may still be read by kernels in flight on any stream, hence the device-wide wait.
+int evict_plans(stark_ctx* ctx, const NttPlan* keep) {
+    size_t total = 0;
+    for (auto& p : ctx->plans) total += p->table_bytes;
+    if (total <= ctx->table_budget) return STARK_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    while (total > ctx->table_budget) {
+        size_t victim = ctx->plans.size();
+        for (size_t i = 0; i < ctx->plans.size(); i++)
+            if (ctx->plans[i].get() != keep && ctx->plans[i]->table_bytes &&
+                (victim == ctx->plans.size() || ctx->plans[i]->last_use < ctx->plans[victim]->last_use))
+                victim = i;
+        if (victim == ctx->plans.size()) break;
+        total -= ctx->plans[victim]->table_bytes;
+        free_plan(ctx->plans[victim].get());
+        ctx->plans.erase(ctx->plans.begin() + (long)victim);
+    }
+    return STARK_OK;
+}
+
 int get_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, NttPlan** out) {
     for (auto& p : ctx->plans)
         if (p->log_n == log_n && p->inverse == inverse && hostfe::eq(p->root, root)) {
+            p->last_use = ++ctx->use_counter;
             *out = p.get();
             return STARK_OK;
         }
-    return build_plan(ctx, log_n, root, inverse, out);
+    int rc = build_plan(ctx, log_n, root, inverse, out);
+    if (rc != STARK_OK) return rc;
+    (*out)->last_use = ++ctx->use_counter;
+    return evict_plans(ctx, *out);
 }
 
 // root^n == 1 and, for n > 1, root^(n/2) != 1  (n = 2^log_n): the order is exactly n
@@ -445,11 +477,16 @@ int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, si
 
 }  // namespace
 
+// Nothing may unwind across the C ABI: every entry point is a function-try-block.
+#define STARK_CATCH                                              \
+    catch (const std::bad_alloc&) { return STARK_ERR_NOMEM; }    \
+    catch (...) { return STARK_ERR_HIP; }
+
 extern "C" {
 
 int stark_version(void) { return 100; }
 
-int stark_ctx_create(int device, stark_ctx** out) {
+int stark_ctx_create(int device, stark_ctx** out) try {
     if (!out) return STARK_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -463,9 +500,11 @@ int stark_ctx_create(int device, stark_ctx** out) {
     }
     const char* cb = getenv("STARKHIP_CHUNK_MB");
     if (cb && atoi(cb) > 0) ctx->chunk_bytes = (size_t)atoi(cb) << 20;
+    const char* tb = getenv("STARKHIP_TABLE_MB");
+    if (tb && atoi(tb) > 0) ctx->table_budget = (size_t)atoi(tb) << 20;
     *out = ctx;
     return STARK_OK;
-}
+} STARK_CATCH
 
 void stark_ctx_destroy(stark_ctx* ctx) {
     if (!ctx) return;
@@ -483,14 +522,14 @@ const char* stark_last_error(const stark_ctx* ctx) { return ctx ? ctx->err.c_str
 
 void* stark_ctx_stream(stark_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int stark_ctx_synchronize(stark_ctx* ctx) {
+int stark_ctx_synchronize(stark_ctx* ctx) try {
     if (!ctx) return STARK_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
 int stark_twiddle_mul_dev(stark_ctx* ctx, void* d_data, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
-                          unsigned log_order, const uint32_t root_of_unity[8], int inverse, void* stream) {
+                          unsigned log_order, const uint32_t root_of_unity[8], int inverse, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (!root_of_unity || (rows && cols && !d_data)) return fail(ctx, STARK_ERR_INVALID, "null argument");
     if (log_order > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_order %u above 30", log_order);
@@ -525,26 +564,26 @@ int stark_twiddle_mul_dev(stark_ctx* ctx, void* d_data, size_t rows, size_t cols
                                     (const uint32_t*)tab->tables[0], (const uint32_t*)tab->tables[1],
                                     stream ? (hipStream_t)stream : ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
-int stark_permute3_dev(stark_ctx* ctx, const void* d_in, void* d_out, size_t a, size_t b, size_t chunk, void* stream) {
+int stark_permute3_dev(stark_ctx* ctx, const void* d_in, void* d_out, size_t a, size_t b, size_t chunk, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (a && b && chunk && (!d_in || !d_out || d_in == d_out)) return fail(ctx, STARK_ERR_INVALID, "null or aliased buffers");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_permute3(d_in, d_out, a, b, chunk, stream ? (hipStream_t)stream : ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
 int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
-                        const uint32_t root_of_unity[8], int inverse, void* stream) {
+                        const uint32_t root_of_unity[8], int inverse, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (!root_of_unity || (batch && (!d_in || !d_out))) return fail(ctx, STARK_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ntt_common(ctx, d_in, d_out, log_n, batch, root_of_unity, inverse, stream ? (hipStream_t)stream : ctx->stream);
-}
+} STARK_CATCH
 
 int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch, const uint32_t root_of_unity[8],
-                    int inverse) {
+                    int inverse) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (!root_of_unity || (batch && !limbs)) return fail(ctx, STARK_ERR_INVALID, "null argument");
     if (log_n > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 30", log_n);
@@ -562,7 +601,7 @@ int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batc
     HIP_TRY(ctx, hipMemcpyAsync(limbs, ctx->io, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
 static int fft_host(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root[8], const uint32_t modulus[8],
                     uint32_t* out, int inverse) {
@@ -579,19 +618,19 @@ static int fft_host(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t 
 }
 
 int stark_fft_inv(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8],
-                  const uint32_t modulus[8], uint32_t* out) {
+                  const uint32_t modulus[8], uint32_t* out) try {
     return fft_host(ctx, v, n, root_of_unity, modulus, out, 1);
-}
+} STARK_CATCH
 
 int stark_fft(stark_ctx* ctx, const uint32_t* v, size_t n, const uint32_t root_of_unity[8], const uint32_t modulus[8],
-              uint32_t* out) {
+              uint32_t* out) try {
     return fft_host(ctx, v, n, root_of_unity, modulus, out, 0);
-}
+} STARK_CATCH
 
 int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const void* d_siblings, uint32_t value_size,
                                   const void* d_witnesses, uint32_t num_witnesses, const void* d_indices,
                                   const void* d_roots, const void* d_root_ids, size_t n, void* d_accept,
-                                  void* d_digests, void* stream) {
+                                  void* d_digests, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (num_witnesses < 1 || num_witnesses > 30)
         return fail(ctx, STARK_ERR_INVALID, "num_witnesses %u outside 1..30", num_witnesses);
@@ -606,12 +645,12 @@ int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const vo
                                       (const uint8_t*)d_roots, (const uint32_t*)d_root_ids, n, (uint8_t*)d_accept,
                                       (uint8_t*)d_digests, stream ? (hipStream_t)stream : ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
 int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
                               const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
                               const uint8_t* roots, uint32_t num_roots, const uint32_t* root_ids, size_t n,
-                              uint8_t* accept, uint8_t* digests) {
+                              uint8_t* accept, uint8_t* digests) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (num_witnesses < 1 || num_witnesses > 30)
         return fail(ctx, STARK_ERR_INVALID, "num_witnesses %u outside 1..30", num_witnesses);
@@ -647,9 +686,9 @@ int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8
     if (digests) HIP_TRY(ctx, hipMemcpyAsync(digests, d_dig, n * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return STARK_OK;
-}
+} STARK_CATCH
 
-int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) {
+int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (op < 0 || op > 7) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);
     if (n == 0) return STARK_OK;
@@ -665,14 +704,14 @@ int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b,
     HIP_TRY(ctx, hipMemcpyAsync(r, dr, n * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return STARK_OK;
-}
+} STARK_CATCH
 
-int stark_fill_random_field_dev(stark_ctx* ctx, void* d_out, size_t n, uint64_t seed, void* stream) {
+int stark_fill_random_field_dev(stark_ctx* ctx, void* d_out, size_t n, uint64_t seed, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (n && !d_out) return fail(ctx, STARK_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_fill_random_field((uint32_t*)d_out, n, seed, stream ? (hipStream_t)stream : ctx->stream));
     return STARK_OK;
-}
+} STARK_CATCH
 
 }  // extern "C"

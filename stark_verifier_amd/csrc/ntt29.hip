@@ -336,7 +336,6 @@ extern "C" int stark_debug_read_stamps(unsigned long long* out) {
 template <int LOGT>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
-    if (const char* x = getenv("STARKHIP_LDS_EXTRA")) lds += (size_t)atoi(x);  // occupancy experiments
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
     if (threads > 1024 || lds > 160 * 1024) return hipErrorInvalidConfiguration;
     static bool attr_set[64] = {};  // per device: dynamic LDS above 64 KiB must be opted into

@@ -343,3 +343,19 @@ def test_cpp_host_mirror_binary(sv):
     r = subprocess.run([exe, os.path.join(root, "tests", "golden", "proof.bin")], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode == 0 and "host mirror ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_twiddle_table_cache_eviction_keeps_results_exact(sv, monkeypatch):
+    """With a 1 MiB table budget every new size evicts the previous plans; results must not change."""
+    monkeypatch.setenv("STARKHIP_TABLE_MB", "1")
+    ctx = sv.Context(0)
+    try:
+        for rep in range(2):
+            for log_n in (13, 14, 15, 13):
+                w = root_of_unity(log_n)
+                x = synth.field_elements(500 + log_n, 1 << log_n)
+                got = sv.fft.ntt_batch(x, w, inverse=bool(rep), ctx=ctx)
+                exp = oracle.fft_inv(x, w) if rep else oracle.fft_fwd(x, w)
+                assert np.array_equal(got, exp), (rep, log_n)
+    finally:
+        ctx.close()
