@@ -32,3 +32,21 @@ def verify_mimc_batch(proofs: Sequence[bytes], inp: int, num_steps: int, round_c
                                               num_steps, rc.ctypes.data if rc.size else None, len(round_constants), _ptr(o),
                                               accept.ctypes.data if n else None, status.ctypes.data if n else None))
     return accept, status
+
+
+def verify_mimc_batch_sharded(proofs: Sequence[bytes], inp: int, num_steps: int, round_constants: Sequence[int], output: int,
+                              ctx: _lib.Context | None = None, verify=None):
+    """The same batch split over the ranks of the default process group (one process per GPU): proofs are
+    independent (the reference's verify_mimc_proof keeps no state between calls, src/lib.rs:99), so rank r
+    verifies the contiguous slice `shard_range(len(proofs), r, world)` and the per-proof flags are gathered
+    (the only exchange). Every rank gets the full (accept, status) vectors. `verify` replaces the device
+    call (CPU tests of the partitioning)."""
+    from .sharding import gather_accept_bits, shard_range
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    lo, hi = shard_range(len(proofs), rank, world)
+    fn = verify or (lambda blobs: verify_mimc_batch(blobs, inp, num_steps, round_constants, output, ctx))
+    accept, status = fn(list(proofs[lo:hi]))
+    return gather_accept_bits(accept, len(proofs)), gather_accept_bits(status, len(proofs))

@@ -146,3 +146,42 @@ def test_device_field_checks_agree_with_host_checks(proof_bytes, monkeypatch):
     monkeypatch.delenv("STARKHIP_BATCH_FIELD")
     a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
     assert a[0] == 1 and not a[1:].any() and set(s[1:].tolist()) == {4}
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+root_dir = sys.argv[1]
+sys.path.insert(0, root_dir); sys.path.insert(0, os.path.join(root_dir, "tests"))
+import ref_verifier as rv
+from stark_verifier_amd import batch
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+good = open(os.path.join(root_dir, "tests", "golden", "proof.bin"), "rb").read()
+bad = bytearray(good); bad[len(good) // 3] ^= 2; bad = bytes(bad)
+blobs = [good, bad, good, good, bad, good, good]
+consts = rv.mimc_constants()
+acc, st = batch.verify_mimc_batch_sharded(blobs, 3, 8192, consts, rv.mimc(3, 8192, consts))
+assert list(acc) == [1, 0, 1, 1, 0, 1, 1], list(acc)
+assert list(st) == [0, 4, 0, 0, 4, 0, 0], list(st)
+dist.barrier()
+if rank == 0:
+    print("ok")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharded_batch_verify(tmp_path):
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(script), root], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ok" in r.stdout

@@ -105,3 +105,38 @@ def test_two_rank_gloo_accept_bit_gather(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ok" in r.stdout
+
+
+BATCH_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from stark_verifier_amd import batch
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+proofs = [bytes([i]) * (i + 1) for i in range(11)]
+seen = []
+def fake(blobs):   # stands in for the device call: accepts even-valued proofs, status = first byte
+    seen.extend(blobs)
+    return (np.array([b[0] % 2 == 0 for b in blobs], dtype=np.uint8), np.array([b[0] for b in blobs], dtype=np.uint8))
+acc, st = batch.verify_mimc_batch_sharded(proofs, 3, 8192, [1], 5, verify=fake)
+assert list(acc) == [1, 0] * 5 + [1] and list(st) == list(range(11))
+assert len(seen) in (5, 6) and all(p in proofs for p in seen)   # each rank saw only its slice
+if rank == 0:
+    print("ok")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_batch_partitioning(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(BATCH_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ok" in r.stdout
