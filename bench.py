@@ -78,7 +78,7 @@ def build_merkle_case(n: int, depth: int, seed: int, corrupt_every: int = 100):
     return values, sibs, np.ascontiguousarray(wit), idx, nodes[1].copy(), expect
 
 
-def timed_region(fn, steps: int, warmup: int, world: int, device):
+def timed_region(fn, steps: int, warmup: int, world: int, coll_device):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
     Returns (seconds, max over ranks) and the mean per-step device time from events."""
     for _ in range(warmup):
@@ -99,7 +99,7 @@ def timed_region(fn, steps: int, warmup: int, world: int, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if steps else 0.0
@@ -145,13 +145,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL; STARKHIP_BENCH_BACKEND=gloo rehearses the multi-rank path with several
+    # ranks sharing one card (its numbers mean nothing)
+    backend = os.environ.get("STARKHIP_BENCH_BACKEND", "nccl")
+    local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     ctx = sv.Context(local_rank)
     # all work of this process goes to one non-default torch stream, so that the library's
     # launches and the timing events are on the same queue
@@ -178,7 +186,7 @@ def main():
     torch.cuda.synchronize()
     roundtrip_ok = bool(torch.equal(x, z))
     del z
-    dt_ntt, dev_ms_ntt = timed_region(ntt_step, args.steps, args.warmup, world, device)
+    dt_ntt, dev_ms_ntt = timed_region(ntt_step, args.steps, args.warmup, world, coll_device)
 
     # ---- region B: depth-`depth` Merkle branch verification ----
     case = build_merkle_case(args.merkle_n, args.depth, SEED + 4 + rank)
@@ -196,9 +204,9 @@ def main():
     merkle_step()
     torch.cuda.synchronize()
     accept_ok = bool(np.array_equal(acc.cpu().numpy(), expect))
-    dt_mk, dev_ms_mk = timed_region(merkle_step, args.steps, args.warmup, world, device)
+    dt_mk, dev_ms_mk = timed_region(merkle_step, args.steps, args.warmup, world, coll_device)
 
-    ok = torch.tensor([int(roundtrip_ok and accept_ok)], device=device)
+    ok = torch.tensor([int(roundtrip_ok and accept_ok)], device=coll_device)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
