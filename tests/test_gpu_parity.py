@@ -359,3 +359,30 @@ def test_twiddle_table_cache_eviction_keeps_results_exact(sv, monkeypatch):
                 assert np.array_equal(got, exp), (rep, log_n)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("log_n,batches", [(0, (1, 5)), (1, (1, 7)), (2, (1, 255, 257)), (3, (3, 130)), (5, (1, 33)),
+                                           (6, (17,)), (8, (5,)), (9, (3,)), (11, (3,)), (12, (1, 2)), (13, (3,)), (15, (5,))])
+def test_ntt_ragged_batches(sv, log_n, batches):
+    """Batch counts that do not fill the last workgroup (several polynomials share a workgroup when the
+    transform is small), including a single polynomial."""
+    n = 1 << log_n
+    w = root_of_unity(log_n)
+    for batch in batches:
+        x = synth.field_elements(9000 + 31 * log_n + batch, batch * n).reshape(batch, n, 8)
+        for inverse in (False, True):
+            got = sv.fft.ntt_batch(x, w, inverse=inverse)
+            for b in sorted({0, batch // 2, batch - 1}):
+                exp = oracle.fft_inv(x[b], w) if inverse else oracle.fft_fwd(x[b], w)
+                assert np.array_equal(got[b], exp), (log_n, batch, inverse, b)
+            # every polynomial against the round trip
+            if not inverse:
+                assert np.array_equal(sv.fft.ntt_batch(got, w, inverse=True), x), (log_n, batch)
+
+
+def test_ntt_empty_batch_is_a_no_op(sv):
+    ctx = sv.default_context()
+    w = root_of_unity(4)
+    r = sv.fft._limbs(w)
+    assert ctx.lib.stark_ntt_batch(ctx.handle, None, 4, 0, sv.fft._ptr(r), 0) == 0
+    assert ctx.lib.stark_ntt_batch_dev(ctx.handle, None, None, 4, 0, sv.fft._ptr(r), 0, None) == 0
