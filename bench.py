@@ -37,6 +37,8 @@ OPS_PER_BUTTERFLY = 152          # 128 IMAD32 + 24 add/sub-with-carry
 OPS_PER_COMPRESSION = 1136       # 80 G x 14 + 16 finalisation xors
 PEAK_VALU_TOPS = 78.6            # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, full-rate 32-bit VALU
 PEAK_HBM_GBPS = 8000.0
+IMAD_PER_BUTTERFLY = 128         # the 32x32->64 multiply-adds inside the 152
+PEAK_IMAD_TOPS_MEASURED = 34.4   # v_mad_u64_u32 lane-ops/s on this chip (stark_verifier_amd/csrc/microbench.hip, 8 waves/SIMD)
 
 
 def measured_traffic(kernel: str, units: float):
@@ -244,6 +246,9 @@ def main():
                 "bound": "valu", "kernel": "ntt29_pass_kernel<%d>" % (log_n if passes == 1 else (log_n + 1) // 2),
                 "achieved": ntt_tops, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (32-bit integer lane-ops)",
                 "frac": ntt_tops / PEAK_VALU_TOPS, "launch_us": launch_s * 1e6, "launches_per_step": launches,
+                # the same work counted in multiply-adds only, against the measured multiply-add issue rate
+                "imad_achieved": ntt_tops * IMAD_PER_BUTTERFLY / OPS_PER_BUTTERFLY, "imad_peak_measured": PEAK_IMAD_TOPS_MEASURED,
+                "imad_frac": ntt_tops * IMAD_PER_BUTTERFLY / OPS_PER_BUTTERFLY / PEAK_IMAD_TOPS_MEASURED,
                 "hbm_achieved_GBps": bytes_per_launch / launch_s * 1e-9, "hbm_frac": bytes_per_launch / launch_s * 1e-9 / PEAK_HBM_GBPS,
                 "traffic": measured_traffic("ntt29_pass_kernel<%d>" % ((log_n + 1) // 2), B / (launches / passes)) if passes == 2 else None,
             },

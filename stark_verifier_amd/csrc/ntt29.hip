@@ -283,9 +283,26 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 lds_put29(lds, plane, at(c, d), y0);
                 lds_put29(lds, plane, at(c, d + (2u << ns_log)), y2);
             }
+            // the inter-pass twiddles of the first two outputs are requested before the last multiplication
+            // of the butterfly, the other two one multiplication ahead of their use
+            const bool tw_on = last && valid && a.TW != nullptr;
+            const uint32_t* tw = a.TW + 8 * (hi * a.twA + lo * a.twB + c * a.twC);
+            Fe t0, t1;
+            if (tw_on) {
+                t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
+                t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
+            }
             F29 a3 = f29_mul(f29_sub(x1, x3), f29_load_raw(a.W + 12 * (size_t)Q));
             y1 = f29_add(a1, a3);
             y3 = f29_sub(a1, a3);
+            if (tw_on) {
+                Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
+                y0 = f29_mul(y0, f29_from_fe(t0));
+                Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
+                y1 = f29_mul(y1, f29_from_fe(t1));
+                y2 = f29_mul(y2, f29_from_fe(t2));
+                y3 = f29_mul(y3, f29_from_fe(t3));
+            }
         }
         if (!last) {
             lds_put29(lds, plane, at(c, d + (1u << ns_log)), y1);
@@ -294,17 +311,17 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             else __syncthreads();  // the next round's inputs come from other wavefronts
             STAMP(1 + round);
         } else if (valid) {
-            if (a.TW || a.has_scale) {
+            if (!a.TW && a.has_scale) {
                 Fe s;
 #pragma unroll
                 for (int l = 0; l < 8; l++) s.l[l] = a.scale[l];
-                const uint32_t* tw = a.TW ? a.TW + 8 * (hi * a.twA + lo * a.twB + c * a.twC) : nullptr;
-                y0 = f29_mul(y0, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)j * a.twS)) : s));
-                y1 = f29_mul(y1, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS)) : s));
-                y2 = f29_mul(y2, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS)) : s));
-                y3 = f29_mul(y3, f29_from_fe(tw ? fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS)) : s));
+                const F29 sc = f29_from_fe(s);
+                y0 = f29_mul(y0, sc);
+                y1 = f29_mul(y1, sc);
+                y2 = f29_mul(y2, sc);
+                y3 = f29_mul(y3, sc);
             }
-            uint32_t* dst = a.out + out_w * ((a.abl & 2 ? 0 : poly) + hi * a.outA + (a.abl & 2 ? lo & 7 : lo) * a.outB + c * a.outC);
+            uint32_t* dst = a.out + out_w * (poly + hi * a.outA + lo * a.outB + c * a.outC);
             const uint64_t s = (uint64_t)out_w * a.outS;
             if (a.out_raw) {
                 f29_store_raw(dst + s * j, y0);
@@ -352,7 +369,6 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
     static const int sl = getenv("STARKHIP_STORE_LOCAL") ? atoi(getenv("STARKHIP_STORE_LOCAL")) : 0;
     static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 3;  // log2 of tiles per L2 group, -1 = off
     b.store_local = (uint32_t)sl;
-    b.abl = getenv("STARKHIP_ABL") ? atoi(getenv("STARKHIP_ABL")) : 0;
     b.tiles = tiles;
     b.polys = polys;
     b.grp_log = 0;

@@ -314,7 +314,7 @@ def test_merkle_index_out_of_range_matches_oracle(sv):
 
 
 def test_merkle_1m_depth20_full_size_properties(sv):
-    """Full BASELINE size (1M branches, depth 20): accept vector known by construction."""
+    """Full benchmark size (1M branches, depth 20): accept vector known by construction."""
     n, w = 1 << 20, 19
     case = synth.merkle_case(77, w, n)
     rng = np.random.default_rng(3)

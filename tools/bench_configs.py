@@ -1,4 +1,4 @@
-"""Device-time measurements of the other BASELINE configurations (the headline one is bench.py):
+"""Device-time measurements of the other benchmark configurations (the headline one is bench.py):
 cfg 2 = 1024 x 2^16 forward + inverse, cfg 3 = one 2^24 transform (single call and the sharded code
 path on one rank), plus 2^20 inverse. Prints one JSON object."""
 import json, os, sys, time
