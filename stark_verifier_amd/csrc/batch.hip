@@ -521,6 +521,8 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
     // diagnostic: let the scalar checks decide even when a branch mismatched (compares the host and device
     // versions of those checks on corrupted values); never set in production
     const bool skip_merkle = getenv("STARKHIP_BATCH_IGNORE_MERKLE") != nullptr;
+    const char* menv = getenv("STARKHIP_BATCH_MERKLE");
+    const bool force_flatten = menv && strcmp(menv, "flatten") == 0;
     CheckParams CP;
     uint32_t* d_mini = nullptr;
     {
@@ -576,12 +578,14 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         // bucket every branch of the chunk by shape; roots are deduplicated per proof
         std::map<std::pair<uint32_t, uint32_t>, Bucket> buckets;
         std::vector<uint8_t> roots;
+        std::vector<uint64_t> root_src;  // offset of each root's 32 bytes inside the chunk
         for (size_t i = 0; i < m; i++) {
             ProofWork& pw = work[i];
             if (pw.status != ST_ACCEPT) continue;
             for (const Query& q : pw.queries) {
                 const uint32_t rid = (uint32_t)(roots.size() / 32);
                 roots.insert(roots.end(), q.root, q.root + 32);
+                root_src.push_back((uint64_t)(q.root - (proofs + offsets[c0])));
                 for (size_t k = 0; k < q.branches->size(); k++) {
                     const BranchRef& b = (*q.branches)[k];
                     Bucket& bk = buckets[{b.vs, b.w}];
@@ -597,6 +601,81 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         t_bucket += now() - t0;
         std::vector<std::atomic<uint8_t>> merkle_bad(m);
         for (auto& x : merkle_bad) x.store(0);
+        // In-place path: upload the chunk's proof bytes once and let every lane read its branch record where
+        // it lies; needs every field at a multiple of 4 bytes. Otherwise (or with STARKHIP_BATCH_MERKLE=flatten)
+        // the branches are copied into structure-of-arrays buffers on the host first.
+        const uint8_t* chunk_base = proofs + offsets[c0];
+        const size_t chunk_len = (size_t)(offsets[c1] - offsets[c0]);
+        bool in_place = !force_flatten;
+        for (size_t i = c0; i < c1 && in_place; i++) in_place = (offsets[i] - offsets[c0]) % 4 == 0;
+        for (auto& kv : buckets) in_place = in_place && kv.second.vs % 4 == 0;
+        if (in_place && !buckets.empty()) {
+            t0 = now();
+            size_t total = 0;
+            for (auto& kv : buckets) total += kv.second.br.size();
+            std::vector<uint64_t> rec_off(total), root_off(total);
+            std::vector<uint32_t> idx(total), pid(total);
+            std::vector<size_t> starts;
+            {
+                size_t o = 0;
+                for (auto& kv : buckets) {
+                    starts.push_back(o);
+                    o += kv.second.br.size();
+                }
+            }
+            {
+                size_t bi = 0;
+                for (auto& kv : buckets) {
+                    Bucket& bk = kv.second;
+                    const size_t base = starts[bi++], n = bk.br.size();
+                    parallel_for((n + 65535) / 65536, threads, [&](size_t blk) {
+                        const size_t lo = blk * 65536, hi = std::min(n, lo + 65536);
+                        for (size_t k = lo; k < hi; k++) {
+                            rec_off[base + k] = (uint64_t)(bk.br[k]->value - chunk_base);
+                            root_off[base + k] = (uint64_t)(&roots[32 * (size_t)bk.root_id[k]] - roots.data());  // replaced below
+                            idx[base + k] = bk.idx[k];
+                            pid[base + k] = bk.proof_id[k];
+                        }
+                    });
+                }
+            }
+            // roots live in the proofs themselves: root ids -> offsets of those 32 bytes inside the chunk
+            for (size_t k = 0; k < total; k++) root_off[k] = root_src[root_off[k] / 32];
+            t_flatten += now() - t0;
+            t0 = now();
+            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t o_rec = up(chunk_len), o_root = o_rec + up(8 * total), o_idx = o_root + up(8 * total),
+                         o_acc = o_idx + up(4 * total), bytes = o_acc + up(total);
+            uint8_t* d = nullptr;
+            if (hipMalloc((void**)&d, bytes) != hipSuccess) {
+                (void)hipFree(d_mini);
+                return STARK_ERR_NOMEM;
+            }
+            hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+            std::vector<uint8_t> acc(total);
+            hipError_t e = hipMemcpyAsync(d, chunk_base, chunk_len, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + o_rec, rec_off.data(), 8 * total, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + o_root, root_off.data(), 8 * total, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + o_idx, idx.data(), 4 * total, hipMemcpyHostToDevice, st);
+            size_t bi = 0;
+            for (auto& kv : buckets) {
+                const size_t base = starts[bi++], n = kv.second.br.size();
+                if (e == hipSuccess)
+                    e = launch_merkle_gather(d, (const uint64_t*)(d + o_rec) + base, kv.second.vs, kv.second.w,
+                                             (const uint32_t*)(d + o_idx) + base, (const uint64_t*)(d + o_root) + base, n,
+                                             d + o_acc + base, st);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(acc.data(), d + o_acc, total, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            (void)hipFree(d);
+            if (e != hipSuccess) {
+                (void)hipFree(d_mini);
+                return STARK_ERR_HIP;
+            }
+            for (size_t k = 0; k < total; k++)
+                if (!acc[k]) merkle_bad[pid[k]].store(1);
+            t_merkle += now() - t0;
+        } else
         for (auto& kv : buckets) {
             Bucket& bk = kv.second;
             const size_t n = bk.br.size();

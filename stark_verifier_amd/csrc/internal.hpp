@@ -60,6 +60,11 @@ hipError_t launch_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_
 // synthetic canonical field elements from SplitMix64(seed), 4 draws per element
 hipError_t launch_fill_random_field(uint32_t* out, size_t n, uint64_t seed, hipStream_t stream);
 
+// Merkle branches read in place from serialized proofs (merkle.hip)
+hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, uint32_t value_size, uint32_t num_witnesses,
+                                const uint32_t* indices, const uint64_t* root_off, size_t n, uint8_t* accept,
+                                hipStream_t stream);
+
 // ---- protocol-layer field checks of the batch driver (checks.hip) ----
 // One sampled position of one FRI layer (reference src/lib.rs:73-86); byte fields are the proof's own
 // big-endian values, copied as they are.

@@ -130,6 +130,104 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
     }
 }
 
+// ---- gather variant: branches are read where they lie in a serialized proof ----
+// A branch record in the wire format (reference src/deserializer.rs:104-125) is
+//   u32 value_size | value | sibling_value | u32 witness_bytes | witness[0] | witness[1] | ...
+// with every field at a multiple of 4 bytes when value_size is. Lane i reads its record at
+// blob + rec_off[i] (the offset of `value`) and its root at blob + root_off[i], so the host
+// uploads the proof bytes once and writes 20 bytes of descriptor per branch instead of copying
+// ~0.5 KB of branch data into structure-of-arrays form. All records of one launch share
+// (value_size, num_witnesses). 16-byte loads at 4-byte alignment.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint4 load16_a4(const uint8_t* p) {
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <bool VS32>
+__global__ void __launch_bounds__(256)
+merkle_gather_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off, uint32_t value_size,
+                     uint32_t num_witnesses, const uint32_t* __restrict__ indices,
+                     const uint64_t* __restrict__ root_off, size_t n, uint8_t* __restrict__ accept) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t a = indices[i];
+    uint32_t ld4_log = num_witnesses - 1;
+    uint32_t idx = (a >> ld4_log) + 4u * (a & ((1u << ld4_log) - 1u));
+    const uint8_t* rec = blob + rec_off[i];
+    const uint8_t* wit = rec + 2 * (size_t)value_size + 4;
+    uint32_t h[8];
+    uint32_t m[16];
+    uint4 w_lo = load16_a4(wit), w_hi = load16_a4(wit + 16);
+    if (VS32) {
+        const uint4 v0 = load16_a4(rec), v1 = load16_a4(rec + 16);
+        const uint4 s0 = load16_a4(rec + 32), s1 = load16_a4(rec + 48);
+        const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t odd = 0u - (idx & 1u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            m[j] = pick(odd, sw[j], vw[j]);
+            m[8 + j] = pick(odd, vw[j], sw[j]);
+        }
+        b2s_hash64(h, m);
+    } else {
+        const uint8_t* v = rec;
+        const uint8_t* s = rec + value_size;
+        const uint8_t* first = (idx & 1u) ? s : v;
+        const uint8_t* second = (idx & 1u) ? v : s;
+        uint32_t total = 2 * value_size;
+        uint32_t nblocks = (total + 63) / 64;
+        b2s_init(h);
+        for (uint32_t b = 0; b < nblocks; b++) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) m[j] = leaf_word(first, second, value_size, 16 * b + j, true);
+            bool last = (b + 1 == nblocks);
+            b2s_compress(h, m, last ? total : 64 * (b + 1), last);
+        }
+    }
+    uint32_t pos = idx >> 1;
+    for (uint32_t l = 0; l < num_witnesses; l++) {
+        uint4 c_lo = w_lo, c_hi = w_hi;
+        if (l + 1 < num_witnesses) {
+            const uint8_t* np = wit + 32 * (size_t)(l + 1);
+            w_lo = load16_a4(np);
+            w_hi = load16_a4(np + 16);
+        }
+        const uint32_t ww[8] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w, c_hi.x, c_hi.y, c_hi.z, c_hi.w};
+        const uint32_t odd = 0u - (pos & 1u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            m[j] = pick(odd, ww[j], h[j]);
+            m[8 + j] = pick(odd, h[j], ww[j]);
+        }
+        b2s_hash64(h, m);
+        pos >>= 1;
+    }
+    const uint8_t* rp = blob + root_off[i];
+    const uint4 r0 = load16_a4(rp), r1 = load16_a4(rp + 16);
+    const uint32_t rt[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    uint32_t diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= h[j] ^ rt[j];
+    accept[i] = diff == 0 ? 1 : 0;
+}
+
+// value_size must be a multiple of 4 and every offset a multiple of 4 (checked by the caller)
+hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, uint32_t value_size, uint32_t num_witnesses,
+                                const uint32_t* indices, const uint64_t* root_off, size_t n, uint8_t* accept,
+                                hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    if (value_size == 32)
+        hipLaunchKernelGGL(merkle_gather_kernel<true>, grid, block, 0, stream, blob, rec_off, value_size, num_witnesses,
+                           indices, root_off, n, accept);
+    else
+        hipLaunchKernelGGL(merkle_gather_kernel<false>, grid, block, 0, stream, blob, rec_off, value_size, num_witnesses,
+                           indices, root_off, n, accept);
+    return hipGetLastError();
+}
+
 hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
                                 const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
                                 const uint8_t* roots, const uint32_t* root_ids, size_t n, uint8_t* accept,

@@ -185,3 +185,22 @@ def test_two_rank_sharded_batch_verify(tmp_path):
                        timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     assert "ok" in r.stdout
+
+
+def test_in_place_and_flattened_merkle_paths_agree(proof_bytes, monkeypatch):
+    """By default the device reads branch records straight from the uploaded proof bytes (needs 4-byte aligned
+    proof offsets); STARKHIP_BATCH_MERKLE=flatten copies them into structure-of-arrays buffers first. A proof
+    whose length is not a multiple of 4 pushes the rest of its chunk onto the flatten path automatically."""
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    v = _variants(proof_bytes)
+    aligned = [v["good"], v["witness_bit"], v["trace_value_bit"], v["good"], v["root2_bit"], v["lincomb_sibling_bit"]] * 2
+    a1, s1 = batch.verify_mimc_batch(aligned, 3, 8192, consts, output)
+    assert list(a1) == [1, 0, 0, 1, 0, 0] * 2 and list(s1) == [0, 4, 4, 0, 4, 4] * 2
+    misaligned = [v["trailing_bytes"]] + aligned          # 13 extra bytes: every later proof starts off a 4-byte boundary
+    a2, s2 = batch.verify_mimc_batch(misaligned, 3, 8192, consts, output)
+    assert list(a2) == [1] + list(a1) and list(s2) == [0] + list(s1)
+    monkeypatch.setenv("STARKHIP_BATCH_MERKLE", "flatten")
+    a3, s3 = batch.verify_mimc_batch(aligned, 3, 8192, consts, output)
+    assert np.array_equal(a3, a1) and np.array_equal(s3, s1)
