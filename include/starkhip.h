@@ -156,6 +156,17 @@ int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const vo
                                   const void* d_indices, const void* d_roots, const void* d_root_ids,
                                   size_t n, void* d_accept, void* d_digests, void* stream);
 
+/*
+ * get_pseudorandom_indices(seed, count, modulus, excludeMultiplesOf) (reference src/utils.rs:53-94) for n seeds at
+ * once: out[i][0..count) for seeds[i][32]. exclude_multiples_of = 0 is the reference's `None`. STARK_ERR_INVALID
+ * where the reference divides by zero (exclude_multiples_of == 1, or a modulus that reduces to 0).
+ * Callers in the reference: src/lib.rs:56 (per FRI layer) and :149.
+ */
+int stark_pseudorandom_indices(stark_ctx* ctx, const uint8_t* seeds, size_t n, uint32_t count, uint32_t modulus,
+                               uint32_t exclude_multiples_of, uint32_t* out);
+int stark_pseudorandom_indices_dev(stark_ctx* ctx, const void* d_seeds, size_t n, uint32_t count, uint32_t modulus,
+                                   uint32_t exclude_multiples_of, void* d_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Batch driver — verify_mimc_proof (reference src/lib.rs:99-197, with verify_low_degree_proof
  * :31-97) over many serialized proofs (deserializer::from_bytes, src/deserializer.rs:142).

@@ -29,7 +29,7 @@ EXPORTS = [
     "stark_ctx_synchronize", "stark_fft_inv", "stark_fft", "stark_ntt_batch", "stark_ntt_batch_dev",
     "stark_merkle_verify_batch", "stark_merkle_verify_batch_dev", "stark_field_op",
     "stark_fill_random_field_dev", "stark_twiddle_mul_dev", "stark_permute3_dev",
-    "stark_mimc_verify_batch",
+    "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
 ]
 
 
@@ -89,6 +89,10 @@ def load() -> ctypes.CDLL:
     L.stark_permute3_dev.restype = i32
     L.stark_mimc_verify_batch.argtypes = [vp, vp, vp, sz, vp, u64, vp, sz, vp, vp, vp]
     L.stark_mimc_verify_batch.restype = i32
+    L.stark_pseudorandom_indices.argtypes = [vp, vp, sz, u32, u32, u32, vp]
+    L.stark_pseudorandom_indices.restype = i32
+    L.stark_pseudorandom_indices_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]
+    L.stark_pseudorandom_indices_dev.restype = i32
     _lib = L
     return L
 

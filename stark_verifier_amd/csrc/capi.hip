@@ -688,6 +688,37 @@ int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8
     return STARK_OK;
 } STARK_CATCH
 
+int stark_pseudorandom_indices_dev(stark_ctx* ctx, const void* d_seeds, size_t n, uint32_t count, uint32_t modulus,
+                                   uint32_t exclude_multiples_of, void* d_out, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n && count && (!d_seeds || !d_out)) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (exclude_multiples_of == 1) return fail(ctx, STARK_ERR_INVALID, "exclude_multiples_of = 1 divides by zero in the reference");
+    const uint32_t real = exclude_multiples_of ? (uint32_t)(modulus * (exclude_multiples_of - 1) / exclude_multiples_of) : modulus;
+    if (real == 0) return fail(ctx, STARK_ERR_INVALID, "modulus reduces to zero (the reference divides by zero)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_sample_indices((const uint8_t*)d_seeds, n, count, real, exclude_multiples_of, (uint32_t*)d_out,
+                                       stream ? (hipStream_t)stream : ctx->stream));
+    return STARK_OK;
+} STARK_CATCH
+
+int stark_pseudorandom_indices(stark_ctx* ctx, const uint8_t* seeds, size_t n, uint32_t count, uint32_t modulus,
+                               uint32_t exclude_multiples_of, uint32_t* out) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n && count && (!seeds || !out)) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (n == 0 || count == 0) return STARK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = (32 * n + 255) & ~(size_t)255, out_bytes = 4 * n * (size_t)count;
+    int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, in_bytes + out_bytes);
+    if (rc != STARK_OK) return rc;
+    uint8_t* d = (uint8_t*)ctx->io;
+    HIP_TRY(ctx, hipMemcpyAsync(d, seeds, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = stark_pseudorandom_indices_dev(ctx, d, n, count, modulus, exclude_multiples_of, d + in_bytes, ctx->stream);
+    if (rc != STARK_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, d + in_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+} STARK_CATCH
+
 int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (op < 0 || op > 7) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);

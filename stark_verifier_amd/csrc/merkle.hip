@@ -228,6 +228,48 @@ hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, ui
     return hipGetLastError();
 }
 
+// ---- query index sampler: get_pseudorandom_indices (reference src/utils.rs:53-94) ----
+// One lane per seed. hashes = seed || H(seed) || H(H(seed)) || ... until 4*count bytes; index j is the
+// big-endian u32 at byte 4j, reduced mod real_modulus = modulus*(exclude-1)/exclude (or modulus), and with
+// `exclude` mapped past the multiples of it: x -> 1 + x + x/(exclude-1).
+__global__ void __launch_bounds__(64)
+sample_indices_kernel(const uint8_t* __restrict__ seeds, size_t n, uint32_t count, uint32_t real_modulus,
+                      uint32_t exclude, uint32_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h[8];
+    for (int k = 0; k < 8; k++) {
+        const uint8_t* b = seeds + 32 * i + 4 * k;
+        h[k] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    }
+    uint32_t* o = out + (size_t)count * i;
+    for (uint32_t j = 0; j < count; j += 8) {
+        if (j) {  // next 32 bytes of the chain: BLAKE2s of the previous 32
+            uint32_t m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                m[k] = h[k];
+                m[8 + k] = 0;
+            }
+            b2s_init(h);
+            b2s_compress(h, m, 32u, true);
+        }
+        for (uint32_t k = 0; k < 8 && j + k < count; k++) {
+            uint32_t x = __builtin_bswap32(h[k]) % real_modulus;
+            if (exclude) x = 1 + x + x / (exclude - 1);
+            o[j + k] = x;
+        }
+    }
+}
+
+hipError_t launch_sample_indices(const uint8_t* seeds, size_t n, uint32_t count, uint32_t real_modulus, uint32_t exclude,
+                                 uint32_t* out, hipStream_t stream) {
+    if (n == 0 || count == 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_indices_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, seeds, n, count,
+                       real_modulus, exclude, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
                                 const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
                                 const uint8_t* roots, const uint32_t* root_ids, size_t n, uint8_t* accept,

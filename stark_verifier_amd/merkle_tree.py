@@ -103,3 +103,17 @@ class MultiProof:
             idx = np.array([int(indices[i]) & 0xFFFFFFFF for i in ids], dtype=np.uint32)
             accept[ids] = verify_batch(values, sibs, wit, idx, rt, ctx=ctx)
         return accept
+
+
+def get_pseudorandom_indices(seeds, count: int, modulus: int, exclude_multiples_of: int | None = None,
+                             ctx: _lib.Context | None = None) -> np.ndarray:
+    """`utils::get_pseudorandom_indices` (reference src/utils.rs:53) for one 32-byte seed (returns [count]) or a
+    list / [n, 32] array of seeds (returns [n, count]); hash chain and reduction run on the GPU."""
+    ctx = ctx or _lib.default_context()
+    single = isinstance(seeds, (bytes, bytearray))
+    s = np.frombuffer(bytes(seeds), dtype=np.uint8).reshape(1, 32) if single else \
+        np.ascontiguousarray(np.array([np.frombuffer(bytes(x), dtype=np.uint8) for x in seeds]) if not isinstance(seeds, np.ndarray) else seeds, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros((s.shape[0], count), dtype=np.uint32)
+    ctx.check(ctx.lib.stark_pseudorandom_indices(ctx.handle, s.ctypes.data, s.shape[0], count, modulus,
+                                                 exclude_multiples_of or 0, out.ctypes.data))
+    return out[0] if single else out

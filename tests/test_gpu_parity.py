@@ -386,3 +386,22 @@ def test_ntt_empty_batch_is_a_no_op(sv):
     r = sv.fft._limbs(w)
     assert ctx.lib.stark_ntt_batch(ctx.handle, None, 4, 0, sv.fft._ptr(r), 0) == 0
     assert ctx.lib.stark_ntt_batch_dev(ctx.handle, None, None, 4, 0, sv.fft._ptr(r), 0, None) == 0
+
+
+def test_pseudorandom_indices_match_oracle_and_proof(sv, proof_bytes):
+    """utils::get_pseudorandom_indices (src/utils.rs:53-94) on the device: the call sites' shapes
+    (40 of deg/4 and 80 of 65536, excluding multiples of 8) on the proof's own roots, plus other shapes."""
+    proof, _ = proofio.parse_proof(proof_bytes)
+    rng = np.random.default_rng(8)
+    seeds = [proof.l_merkle_root, proof.merkle_root] + [l.root2 for l in proof.fri_layers] + \
+            [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(200)]
+    for count, modulus, excl in ((40, 16384, 8), (80, 65536, 8), (40, 64, 8), (1, 7, None), (8, 2**32 - 1, None), (9, 1000, 2),
+                                 (17, 12345, 3), (64, 65536, None), (100, 5, 5)):
+        got = sv.merkle_tree.get_pseudorandom_indices(seeds, count, modulus, excl)
+        for s, row in zip(seeds, got):
+            assert list(row) == [int(x) for x in oracle.get_pseudorandom_indices(s, count, modulus, excl)], (count, modulus, excl)
+    one = sv.merkle_tree.get_pseudorandom_indices(proof.l_merkle_root, 80, 65536, 8)
+    assert one.shape == (80,) and not (one % 8 == 0).any()
+    for bad in ((40, 16384, 1), (40, 1, 8), (40, 0, None)):
+        with pytest.raises(sv.InvalidArgument):
+            sv.merkle_tree.get_pseudorandom_indices(seeds[:2], *bad)
