@@ -226,7 +226,7 @@ def main():
         ntt_per_s = world * B * K / dt_ntt
         mk_per_s = world * args.merkle_n * K / dt_mk
         # dominant kernel: the tile-transform pass kernel; a step is `launches` launches of it
-        chunk = max(1, min(B, (512 << 20) // (n * 32)))
+        chunk = max(1, min(B, (2048 << 20) // (n * 32)))  # polynomials per group of pass launches (library default)
         passes = 1 if log_n <= 12 else 2
         launches = passes * ((B + chunk - 1) // chunk)
         launch_s = dev_ms_ntt * 1e-3 / launches

@@ -52,7 +52,7 @@ struct stark_ctx {
     size_t scratch_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
-    size_t chunk_bytes = (size_t)512 << 20;  // input bytes transformed per group of pass launches
+    size_t chunk_bytes = (size_t)2048 << 20;  // input bytes transformed per group of pass launches (scratch = 1.5x)
     size_t table_budget = (size_t)8 << 30;   // twiddle tables kept across calls (STARKHIP_TABLE_MB)
     uint64_t use_counter = 0;
 };
