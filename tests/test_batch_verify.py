@@ -204,3 +204,36 @@ def test_in_place_and_flattened_merkle_paths_agree(proof_bytes, monkeypatch):
     monkeypatch.setenv("STARKHIP_BATCH_MERKLE", "flatten")
     a3, s3 = batch.verify_mimc_batch(aligned, 3, 8192, consts, output)
     assert np.array_equal(a3, a1) and np.array_equal(s3, s1)
+
+
+def test_fuzzed_proof_bytes_never_crash_and_match_the_restatement(proof_bytes):
+    """Random damage to header and length fields, truncations and splices: the driver must return (never
+    crash or read out of bounds) and agree with the reference restatement on every proof."""
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    rng = np.random.default_rng(77)
+    n = len(proof_bytes)
+    blobs = []
+    for t in range(120):
+        b = bytearray(proof_bytes)
+        kind = t % 6
+        if kind == 0:      # flip bits near the start (roots, element types, first branch headers)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, 400))] ^= 1 << int(rng.integers(8))
+        elif kind == 1:    # overwrite a 4-byte aligned word somewhere with a huge or tiny length
+            o = 4 * int(rng.integers(16, n // 4 - 1))
+            b[o:o + 4] = struct.pack("<I", int(rng.choice([0, 1, 31, 33, 96, 2**31, 2**32 - 1, 4096])))
+        elif kind == 2:    # truncate
+            b = b[:int(rng.integers(0, n))]
+        elif kind == 3:    # drop a slice (shifts everything after it)
+            o = int(rng.integers(64, n - 200)); b = b[:o] + b[o + 4 * int(rng.integers(1, 20)):]
+        elif kind == 4:    # damage inside the unverified points or anywhere random
+            b[int(rng.integers(0, n))] ^= 0xFF
+        else:              # duplicate a tail
+            b = b + b[-int(rng.integers(1, 5000)):]
+        blobs.append(bytes(b))
+    accept, status = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    expect = [_ref_accepts(b, 3, 8192, consts, output) for b in blobs]
+    assert [bool(a) for a in accept] == expect
+    assert all((s == 0) == bool(a) for a, s in zip(accept, status))
