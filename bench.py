@@ -8,7 +8,7 @@ exchanged: every rank transforms its own batch of polynomials and verifies its o
 there is no data-path collective ("weak" scaling); torch.distributed is used only for the
 barriers and the max-over-ranks of the timed region.
 
-A step of the headline region is one forward NTT of `--ntt-batch` polynomials of 2^20 points,
+A step of the headline region is one forward NTT of `--ntt-batch` (default 64) polynomials of 2^20 points,
 inputs and outputs resident in HBM. A second region, timed the same way, verifies
 `--merkle-n` depth-20 branches per step. Rank 0 prints ONE JSON line.
 """
@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--ntt-batch", type=int, default=32, help="polynomials per step per GPU")
+    ap.add_argument("--ntt-batch", type=int, default=64, help="polynomials per step per GPU")
     ap.add_argument("--merkle-n", type=int, default=1 << 20, help="branches per step per GPU")
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
