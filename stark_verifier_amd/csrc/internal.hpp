@@ -36,7 +36,6 @@ struct NttPassArgs {
     uint32_t canon_in;   // inputs may be any 256-bit value: reduce on load (first pass only)
     uint32_t tiles, polys;  // 29-bit-limb kernels: grid = tiles * polys work items
     uint32_t grp_log;       // 0 = plain order, g + 1 = L2-grouped order with 2^g adjacent tiles per group
-    uint32_t store_local;  // 29-bit-limb kernels: last round keeps the wave-local lane order (no extra exchange)
     uint32_t in_raw, out_raw;  // 29-bit-limb kernels: element is 12 unpacked dwords instead of 8 packed
     uint32_t has_scale;
     uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)

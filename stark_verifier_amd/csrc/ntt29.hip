@@ -3,8 +3,8 @@
 // Same transform and the same pass / tile geometry as described in ntt.hip (what the
 // reference's _fft computes, reference src/fft.rs:37-61, natural order in and out, canonical
 // outputs); what differs is the representation inside the kernel:
-//   * on load an element (8 x 32-bit limbs in HBM) is unpacked to nine 29-bit limbs; LDS holds
-//     nine limb planes per tile;
+//   * on load an element (8 x 32-bit limbs in HBM) is unpacked to nine 29-bit limbs; in LDS an
+//     element is nine adjacent dwords;
 //   * butterfly additions and subtractions are limb-wise v_add_u32 / v_sub_u32 with no carry
 //     chain, the products are carry-free v_mad_u64_u32 columns (field29.cuh);
 //   * between passes of a multi-pass transform the intermediate stays unpacked (12 dwords per
@@ -18,23 +18,21 @@
 
 namespace starkhip {
 
-// Position swizzle inside a tile row: XOR bits 2..6 into bits 0..4. With it both the unit-stride
+// Slot swizzle inside a sub-image: XOR bits 2..6 into bits 0..4. With it both the unit-stride
 // reads (element j + q*T/4) and the strided Stockham writes (stride 4*Ns) of every round land on
-// 32 distinct banks per 32-lane group; without it the writes are up to 4-way conflicted.
+// distinct slots mod 32 per 32-lane group; without it the writes are up to 4-way conflicted.
 __device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 2) & 31u); }
 
 // An element's nine limbs are adjacent in LDS (slot * 9 + limb): one address per element, the
 // limbs at immediate offsets, two per ds_read2/ds_write2. 9 is odd, so slots that differ mod
 // 64 stay on different banks.
-__device__ __forceinline__ void lds_put29(uint32_t* lds, uint32_t plane, uint32_t off, const F29& v) {
-    (void)plane;
+__device__ __forceinline__ void lds_put29(uint32_t* lds, uint32_t off, const F29& v) {
     uint32_t* q = lds + off * 9;
 #pragma unroll
     for (int l = 0; l < 9; l++) q[l] = v.l[l];
 }
 
-__device__ __forceinline__ F29 lds_get29(const uint32_t* lds, uint32_t plane, uint32_t off) {
-    (void)plane;
+__device__ __forceinline__ F29 lds_get29(const uint32_t* lds, uint32_t off) {
     const uint32_t* q = lds + off * 9;
     F29 v;
 #pragma unroll
@@ -74,7 +72,7 @@ struct TileGeom {
     static constexpr uint32_t W = 1u << LW;
     static constexpr uint32_t B = (1u << LOGT) >> LW;   // sub-image length (<= 256)
     static constexpr uint32_t SB = B + (LW ? 8u : 0u);  // sub-image stride: +8 keeps cross-wave rounds off one bank
-    static constexpr uint32_t ROW = W * SB;             // dwords of one limb plane of one tile
+    static constexpr uint32_t ROW = W * SB;             // element slots of one tile
 };
 
 __host__ __device__ inline uint32_t tile_pad29(uint32_t log_c) {
@@ -115,7 +113,6 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
 
     const uint32_t log_c = a.log_c, C = 1u << log_c;
     const uint32_t Tp = G::ROW + tile_pad29(log_c);
-    const uint32_t plane = Tp << log_c;
     const uint32_t tid = threadIdx.x;
     const uint32_t in_w = a.in_raw ? 12u : 8u, out_w = a.out_raw ? 12u : 8u;
     // Work item -> (tile, polynomial). Workgroups are dealt round-robin over the 8 XCDs, each with
@@ -135,7 +132,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     const uint32_t hi = tau >> a.dsh, lo = tau & a.dmask;
     const uint64_t poly = (uint64_t)pidx * a.poly_stride;
 
-    // LDS dword offset (within a limb plane) of position p of tile c
+    // LDS slot of position p of tile c (an element occupies nine dwords at slot * 9)
     auto at = [&](uint32_t c, uint32_t p) -> uint32_t {
         return c * Tp + (p & (G::W - 1)) * G::SB + swz(p >> LW);
     };
@@ -162,7 +159,6 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     };
     // the element-fastest edge order coincides with the local order when a tile is one wavefront or less
     const bool load_is_local = !a.load_cfast && LW == 0;
-    const bool store_local = a.store_local != 0;
 
     // global -> registers for the lane's four inputs (first round; zeros for tiles past the end)
     auto load_inputs = [&](uint32_t c, uint32_t j, bool valid) -> Quad29 {
@@ -190,7 +186,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // Is the exchange after a round confined to each wavefront's own sub-image? (the round and the
     // next one both run in the local lane order, and Ns >= W keeps the low bits of j)
     auto exchange_is_local = [&](int round, bool local, uint32_t ns_now, uint32_t ns_next) {
-        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !store_local && !(!a.store_cfast && LW == 0);
+        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !(!a.store_cfast && LW == 0);
         return round != ROUNDS - 1 && local && ns_now >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
     };
 
@@ -205,10 +201,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         const Quad29 q = load_inputs(c, j, valid);
         const F29 &x0 = q.a, &x1 = q.b, &x2 = q.c, &x3 = q.d;
         F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
-        lds_put29(lds, plane, at(c, 2 * j), y0);
-        lds_put29(lds, plane, at(c, 2 * j + 1), y1);
-        lds_put29(lds, plane, at(c, 2 * (j + Q)), y2);
-        lds_put29(lds, plane, at(c, 2 * (j + Q) + 1), y3);
+        lds_put29(lds, at(c, 2 * j), y0);
+        lds_put29(lds, at(c, 2 * j + 1), y1);
+        lds_put29(lds, at(c, 2 * (j + Q)), y2);
+        lds_put29(lds, at(c, 2 * (j + Q) + 1), y3);
         if (exchange_is_local(0, load_is_local, 0, 1)) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
         ns_log = 1;
@@ -222,7 +218,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         if (first) {
             local = load_is_local;
             edge_map(a.load_cfast, c, j);
-        } else if (last && !store_local) {
+        } else if (last) {
             local = !a.store_cfast && LW == 0;
             edge_map(a.store_cfast, c, j);
         } else if (ns_log >= (uint32_t)LW) {
@@ -247,10 +243,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             x2 = q.c;
             x3 = q.d;
         } else {
-            x0 = lds_get29(lds, plane, at(c, j));
-            x1 = lds_get29(lds, plane, at(c, j + Q));
-            x2 = lds_get29(lds, plane, at(c, j + 2 * Q));
-            x3 = lds_get29(lds, plane, at(c, j + 3 * Q));
+            x0 = lds_get29(lds, at(c, j));
+            x1 = lds_get29(lds, at(c, j + Q));
+            x2 = lds_get29(lds, at(c, j + 2 * Q));
+            x3 = lds_get29(lds, at(c, j + 3 * Q));
         }
         const bool out_local = exchange_is_local(round, local, ns_log, ns_log + 2);
         if (!first) {
@@ -280,8 +276,8 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             y0 = f29_add(a0, a2);
             y2 = f29_sub2(a0, a2);
             if (!last) {  // these two do not wait for the multiplication by I
-                lds_put29(lds, plane, at(c, d), y0);
-                lds_put29(lds, plane, at(c, d + (2u << ns_log)), y2);
+                lds_put29(lds, at(c, d), y0);
+                lds_put29(lds, at(c, d + (2u << ns_log)), y2);
             }
             // the inter-pass twiddles of the first two outputs are requested before the last multiplication
             // of the butterfly, the other two one multiplication ahead of their use
@@ -305,8 +301,8 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             }
         }
         if (!last) {
-            lds_put29(lds, plane, at(c, d + (1u << ns_log)), y1);
-            lds_put29(lds, plane, at(c, d + (3u << ns_log)), y3);
+            lds_put29(lds, at(c, d + (1u << ns_log)), y1);
+            lds_put29(lds, at(c, d + (3u << ns_log)), y3);
             if (out_local) __builtin_amdgcn_wave_barrier();
             else __syncthreads();  // the next round's inputs come from other wavefronts
             STAMP(1 + round);
@@ -366,9 +362,7 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
         if (dev < 64) attr_set[dev] = true;
     }
     NttPassArgs b = a;
-    static const int sl = getenv("STARKHIP_STORE_LOCAL") ? atoi(getenv("STARKHIP_STORE_LOCAL")) : 0;
     static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 3;  // log2 of tiles per L2 group, -1 = off
-    b.store_local = (uint32_t)sl;
     b.tiles = tiles;
     b.polys = polys;
     b.grp_log = 0;
