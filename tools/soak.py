@@ -1,0 +1,50 @@
+"""Randomized soak: transforms and Merkle batches of random shapes against the CPU oracle for a given number of
+seconds. python tools/soak.py [seconds] [seed]. Test infrastructure (uses the oracle); prints a summary line."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle, synth
+import stark_verifier_amd as sv
+
+P = oracle.P
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+n_ntt = n_mk = 0
+while time.time() < t_end:
+    if rng.random() < 0.6:
+        log_n = int(rng.integers(0, 17))
+        n = 1 << log_n
+        batch = int(rng.integers(1, max(2, min(300, (1 << 18) // n))))
+        w = pow(7, (P - 1) >> log_n, P)
+        x = synth.field_elements(int(rng.integers(1 << 30)), batch * n).reshape(batch, n, 8)
+        if rng.random() < 0.3:   # non-canonical 256-bit inputs
+            x = rng.integers(0, 2**32, size=x.shape, dtype=np.uint64).astype(np.uint32)
+        inverse = bool(rng.integers(2))
+        got = sv.fft.ntt_batch(x, w, inverse=inverse)
+        for b in {0, batch - 1, int(rng.integers(batch))}:
+            exp = oracle.fft_inv(x[b], w) if inverse else oracle.fft_fwd(x[b], w)
+            assert np.array_equal(got[b], exp), ("ntt", log_n, batch, inverse, b)
+        n_ntt += 1
+    else:
+        w = int(rng.integers(1, 21))
+        vs = int(rng.choice([32, 32, 32, 36, 64, 96, 100, 33]))
+        n = int(rng.integers(1, 3000))
+        w = min(w, 14)   # the tree itself is built on the CPU
+        case = synth.merkle_case(int(rng.integers(1 << 30)), w, n, vs)
+        wit = case["witnesses"].copy()
+        vals = case["values"].copy()
+        for _ in range(int(rng.integers(0, 5))):
+            if rng.random() < 0.5:
+                wit[int(rng.integers(w)), int(rng.integers(n)), int(rng.integers(32))] ^= 1 << int(rng.integers(8))
+            else:
+                vals[int(rng.integers(n)), int(rng.integers(vs))] ^= 1 << int(rng.integers(8))
+        idx = case["indices"].copy()
+        if rng.random() < 0.3:
+            idx[int(rng.integers(n))] ^= 1
+        acc, dig = sv.merkle_tree.verify_batch(vals, case["siblings"], wit, idx, case["root"], want_digests=True)
+        exp = oracle.merkle_verify_batch(vals, case["siblings"], wit, idx, case["root"])
+        assert np.array_equal(acc, exp), ("merkle", w, vs, n)
+        n_mk += 1
+print("soak ok: %d transform cases, %d merkle cases in %.0f s" % (n_ntt, n_mk, budget))
