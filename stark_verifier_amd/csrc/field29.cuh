@@ -13,8 +13,9 @@
 //
 // Forms
 //   "lazy"  : limbs < 3 * 2^30, any value below 2^261 that is congruent to the element.
-//   "tight" : limbs 0..7 < 2^29, limb 8 <= 2^24, i.e. value < 2^256 + 2^232. f29_mul returns
-//             tight values; table entries (twiddles) are canonical, which is tight.
+//   "tight" : limbs 0..7 < 2^29 (limb 3 may exceed it by less than 2^5), limb 8 < 2^24, i.e. value
+//             < 2^256 + 2^92. f29_mul returns tight values; table entries (twiddles) are canonical,
+//             which is tight.
 // Results leave this representation through f29_to_fe, which returns the canonical residue, so
 // everything observable is bit-identical to exact integer arithmetic mod p (what the
 // reference's BigInt `%` and utils::negative_to_positive produce, reference src/fft.rs:28,53-57,84).
@@ -225,23 +226,20 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
     acc >>= 29;
     acc = mad64(u1, F29_C1, acc + r[2]);
     o.l[2] = (uint32_t)acc & F29_MASK;
-    uint32_t c = (uint32_t)(acc >> 29);  // small: u1*C1 < 2^33, shifted down by 29
+    // what is left above limb 2 is below 2^5 (u1*C1 < 2^33, shifted down by 29): it stays in limb 3
+    // unpropagated, which every consumer of a tight value tolerates
+    o.l[3] = r[3] + (uint32_t)(acc >> 29);
 #pragma unroll
-    for (int i = 3; i < 8; i++) {
-        uint32_t v = r[i] + c;
-        o.l[i] = v & F29_MASK;
-        c = v >> 29;
-    }
-    o.l[8] = r[8] + c;  // <= 2^24
+    for (int i = 4; i < 9; i++) o.l[i] = r[i];
     return o;
 }
 
 // Any lazy value -> canonical residue as 8 x 32-bit limbs.
 __device__ __forceinline__ Fe f29_to_fe(const F29& x) {
     F29 v = f29_carry(x);  // limbs 0..7 < 2^29, limb 8 < 2^32
-    // fold what lies above bit 256: e * 2^256 == e * (2808 * 2^29 - 1)
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
+    // fold what lies above bit 256: e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8. Afterwards the value
+    // is below 2^256 + 2^50 (possibly still at or above 2^256: the subtraction of p below covers that).
+    {
         uint32_t e = v.l[8] >> 24;
         v.l[8] &= 0x00FFFFFFu;
         int32_t s0 = (int32_t)v.l[0] - (int32_t)e;  // may be negative: signed carry below
@@ -258,8 +256,8 @@ __device__ __forceinline__ Fe f29_to_fe(const F29& x) {
         }
         v.l[8] += cc;
     }
-    // now value < 2^256 (second pass folds at most a single 2^256, leaving a tiny remainder).
-    // canonical: subtract p when value >= p, i.e. when value + (2^256 - p) reaches 2^256
+    // canonical: with delta = 2^256 - p, value >= p exactly when value + delta reaches 2^256, and then
+    // value - p = value + delta - 2^256 (value + delta < 2^257, so bit 256 is the whole test)
     F29 u;
     {
         uint32_t t = v.l[0] + F29_C0;
