@@ -236,25 +236,26 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
 
 // Any lazy value -> canonical residue as 8 x 32-bit limbs.
 __device__ __forceinline__ Fe f29_to_fe(const F29& x) {
-    F29 v = f29_carry(x);  // limbs 0..7 < 2^29, limb 8 < 2^32
-    // fold what lies above bit 256: e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8. Afterwards the value
-    // is below 2^256 + 2^50 (possibly still at or above 2^256: the subtraction of p below covers that).
+    // One carry pass that also folds what lies above bit 256 (taken from limb 8 before the carries below it
+    // arrive): e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8, entered as 2^29 - e at limb 0 and 2808 e - 1 at
+    // limb 1. Input limbs are below 3 * 2^30. The value ends below 2^256 + 2^236, limbs 0..7 below 2^29;
+    // it may still be at or above 2^256, which the subtraction of p below covers.
+    F29 v;
     {
-        uint32_t e = v.l[8] >> 24;
-        v.l[8] &= 0x00FFFFFFu;
-        int32_t s0 = (int32_t)v.l[0] - (int32_t)e;  // may be negative: signed carry below
-        v.l[0] = (uint32_t)s0 & F29_MASK;
-        int32_t c = s0 >> 29;
-        uint32_t s1 = v.l[1] + 2808u * e + (uint32_t)c;  // non-negative: e > 0 whenever c < 0
-        v.l[1] = s1 & F29_MASK;
-        uint32_t cc = s1 >> 29;
+        const uint32_t e = x.l[8] >> 24;
+        uint32_t t = x.l[0] + (0x20000000u - e);
+        v.l[0] = t & F29_MASK;
+        uint32_t cc = t >> 29;  // at least 1
+        t = x.l[1] + 2808u * e + cc - 1u;
+        v.l[1] = t & F29_MASK;
+        cc = t >> 29;
 #pragma unroll
         for (int i = 2; i < 8; i++) {
-            uint32_t t = v.l[i] + cc;
+            t = x.l[i] + cc;
             v.l[i] = t & F29_MASK;
             cc = t >> 29;
         }
-        v.l[8] += cc;
+        v.l[8] = (x.l[8] & 0x00FFFFFFu) + cc;
     }
     // canonical: with delta = 2^256 - p, value >= p exactly when value + delta reaches 2^256, and then
     // value - p = value + delta - 2^256 (value + delta < 2^257, so bit 256 is the whole test)
