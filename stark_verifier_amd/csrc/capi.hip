@@ -115,9 +115,10 @@ std::vector<int> choose_split(unsigned log_n) {
         if (sum == (int)log_n && v.size() >= 1 && v.size() <= 3) return v;
     }
     if (log_n <= 12) return {(int)log_n};
-    // two passes while both tiles fit two workgroups per CU (2^11 points); three passes of 2^8-point
-    // tiles beat 2^12-point tiles above that (2^24: 1.94 ms against 2.20 ms)
-    if (log_n <= 22) return {(int)(log_n + 1) / 2, (int)log_n / 2};
+    // two passes up to 2^21, the smaller tile first (its strided side is the costly one); from 2^22 on
+    // three passes of 2^7..2^8-point tiles beat tiles of 2^11..2^12 points (2^22: 3.28 ms against 3.64 ms for 8
+    // transforms, 2^24: 1.94 ms against 2.20 ms)
+    if (log_n <= 21) return {(int)log_n / 2, (int)(log_n + 1) / 2};
     int a = ((int)log_n + 2) / 3, b = ((int)log_n - a + 1) / 2;
     return {a, b, (int)log_n - a - b};
 }
