@@ -116,8 +116,7 @@ std::vector<int> choose_split(unsigned log_n) {
     }
     if (log_n <= 12) return {(int)log_n};
     // two passes up to 2^21, the smaller tile first (its strided side is the costly one); from 2^22 on
-    // three passes of 2^7..2^8-point tiles beat tiles of 2^11..2^12 points (2^22: 3.28 ms against 3.64 ms for 8
-    // transforms, 2^24: 1.94 ms against 2.20 ms)
+    // three passes of 2^7..2^8-point tiles beat tiles of 2^11..2^12 points (measured 10..12 % faster at 2^22 and 2^24)
     if (log_n <= 21) return {(int)log_n / 2, (int)(log_n + 1) / 2};
     int a = ((int)log_n + 2) / 3, b = ((int)log_n - a + 1) / 2;
     return {a, b, (int)log_n - a - b};
