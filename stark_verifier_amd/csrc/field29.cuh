@@ -234,29 +234,33 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
     return o;
 }
 
+// Lazy -> tight without a multiplication: one carry pass that also folds what lies above bit 256 (taken
+// from limb 8 before the carries below it arrive): e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8, entered as
+// 2^29 - e at limb 0 and 2808 e - 1 at limb 1. Input limbs are below 3 * 2^30. The value ends below
+// 2^256 + 2^236 (limbs 0..7 below 2^29, limb 8 below 2^24 + 8).
+__device__ __forceinline__ F29 f29_tighten(const F29& x) {
+    F29 v;
+    const uint32_t e = x.l[8] >> 24;
+    uint32_t t = x.l[0] + (0x20000000u - e);
+    v.l[0] = t & F29_MASK;
+    uint32_t cc = t >> 29;  // at least 1
+    t = x.l[1] + 2808u * e + cc - 1u;
+    v.l[1] = t & F29_MASK;
+    cc = t >> 29;
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        t = x.l[i] + cc;
+        v.l[i] = t & F29_MASK;
+        cc = t >> 29;
+    }
+    v.l[8] = (x.l[8] & 0x00FFFFFFu) + cc;
+    return v;
+}
+
 // Any lazy value -> canonical residue as 8 x 32-bit limbs.
 __device__ __forceinline__ Fe f29_to_fe(const F29& x) {
-    // One carry pass that also folds what lies above bit 256 (taken from limb 8 before the carries below it
-    // arrive): e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8, entered as 2^29 - e at limb 0 and 2808 e - 1 at
-    // limb 1. Input limbs are below 3 * 2^30. The value ends below 2^256 + 2^236, limbs 0..7 below 2^29;
-    // it may still be at or above 2^256, which the subtraction of p below covers.
-    F29 v;
-    {
-        const uint32_t e = x.l[8] >> 24;
-        uint32_t t = x.l[0] + (0x20000000u - e);
-        v.l[0] = t & F29_MASK;
-        uint32_t cc = t >> 29;  // at least 1
-        t = x.l[1] + 2808u * e + cc - 1u;
-        v.l[1] = t & F29_MASK;
-        cc = t >> 29;
-#pragma unroll
-        for (int i = 2; i < 8; i++) {
-            t = x.l[i] + cc;
-            v.l[i] = t & F29_MASK;
-            cc = t >> 29;
-        }
-        v.l[8] = (x.l[8] & 0x00FFFFFFu) + cc;
-    }
+    // it may still be at or above 2^256, which the subtraction of p below covers
+    F29 v = f29_tighten(x);
     // canonical: with delta = 2^256 - p, value >= p exactly when value + delta reaches 2^256, and then
     // value - p = value + delta - 2^256 (value + delta < 2^257, so bit 256 is the whole test)
     F29 u;
