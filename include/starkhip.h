@@ -157,6 +157,17 @@ int stark_merkle_verify_batch_dev(stark_ctx* ctx, const void* d_values, const vo
                                   size_t n, void* d_accept, void* d_digests, void* stream);
 
 /*
+ * Tree construction — no counterpart in the reference (its prover is external, README.md:9); builds the
+ * tree ProofBranch::verify walks: nodes[1] is the root, nodes[i] = BLAKE2s(nodes[2i] || nodes[2i+1]), the
+ * 2^log_leaves 32-byte leaves at nodes[L .. 2L) in the tree's own leaf order (after permute_4_index,
+ * src/merkle_tree.rs:112-116); nodes[0] is unused. Used to make synthetic trees on the device.
+ * Host version: leaves [L][32] in, nodes [2L][32] out. Device version: in place on d_nodes (2L x 32 bytes,
+ * 16-byte aligned, leaves already in the upper half).
+ */
+int stark_merkle_build(stark_ctx* ctx, const uint8_t* leaves, unsigned log_leaves, uint8_t* nodes);
+int stark_merkle_build_dev(stark_ctx* ctx, void* d_nodes, unsigned log_leaves, void* stream);
+
+/*
  * get_pseudorandom_indices(seed, count, modulus, excludeMultiplesOf) (reference src/utils.rs:53-94) for n seeds at
  * once: out[i][0..count) for seeds[i][32]. exclude_multiples_of = 0 is the reference's `None`. STARK_ERR_INVALID
  * where the reference divides by zero (exclude_multiples_of == 1, or a modulus that reduces to 0).

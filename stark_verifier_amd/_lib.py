@@ -30,6 +30,7 @@ EXPORTS = [
     "stark_merkle_verify_batch", "stark_merkle_verify_batch_dev", "stark_field_op",
     "stark_fill_random_field_dev", "stark_twiddle_mul_dev", "stark_permute3_dev",
     "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
+    "stark_merkle_build", "stark_merkle_build_dev",
 ]
 
 
@@ -93,6 +94,10 @@ def load() -> ctypes.CDLL:
     L.stark_pseudorandom_indices.restype = i32
     L.stark_pseudorandom_indices_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]
     L.stark_pseudorandom_indices_dev.restype = i32
+    L.stark_merkle_build.argtypes = [vp, vp, ctypes.c_uint, vp]
+    L.stark_merkle_build.restype = i32
+    L.stark_merkle_build_dev.argtypes = [vp, vp, ctypes.c_uint, vp]
+    L.stark_merkle_build_dev.restype = i32
     _lib = L
     return L
 

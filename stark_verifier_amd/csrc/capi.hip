@@ -688,6 +688,32 @@ int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8
     return STARK_OK;
 } STARK_CATCH
 
+int stark_merkle_build_dev(stark_ctx* ctx, void* d_nodes, unsigned log_leaves, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!d_nodes) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_leaves > 31) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_leaves %u above 31", log_leaves);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_merkle_build((uint8_t*)d_nodes, log_leaves, stream ? (hipStream_t)stream : ctx->stream));
+    return STARK_OK;
+} STARK_CATCH
+
+int stark_merkle_build(stark_ctx* ctx, const uint8_t* leaves, unsigned log_leaves, uint8_t* nodes) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!leaves || !nodes) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_leaves > 31) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_leaves %u above 31", log_leaves);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t L = (size_t)1 << log_leaves;
+    int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, 64 * L);
+    if (rc != STARK_OK) return rc;
+    uint8_t* d = (uint8_t*)ctx->io;
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, 32, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + 32 * L, leaves, 32 * L, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_merkle_build(d, log_leaves, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(nodes, d, 64 * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+} STARK_CATCH
+
 int stark_pseudorandom_indices_dev(stark_ctx* ctx, const void* d_seeds, size_t n, uint32_t count, uint32_t modulus,
                                    uint32_t exclude_multiples_of, void* d_out, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;

@@ -64,6 +64,7 @@ hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, ui
                                 const uint32_t* indices, const uint64_t* root_off, size_t n, uint8_t* accept,
                                 hipStream_t stream);
 
+hipError_t launch_merkle_build(uint8_t* nodes, unsigned log_leaves, hipStream_t stream);
 hipError_t launch_sample_indices(const uint8_t* seeds, size_t n, uint32_t count, uint32_t real_modulus, uint32_t exclude,
                                  uint32_t* out, hipStream_t stream);
 

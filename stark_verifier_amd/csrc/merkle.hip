@@ -270,6 +270,53 @@ hipError_t launch_sample_indices(const uint8_t* seeds, size_t n, uint32_t count,
     return hipGetLastError();
 }
 
+// ---- tree construction (prover side; the reference only verifies) ----
+// nodes[1] is the root, nodes[i] = H(nodes[2i] || nodes[2i+1]), the 2^log_leaves leaves sit at
+// nodes[L .. 2L) (already in the tree's leaf order, i.e. after permute_4_index). One lane per node of a
+// level: 64 contiguous bytes in, 32 out (96 bytes and one compression per node).
+__global__ void __launch_bounds__(256) merkle_level_kernel(uint4* __restrict__ nodes, size_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t i = count + t;
+    const uint4* src = nodes + 4 * i;  // nodes[2i], nodes[2i+1]
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    const uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t h[8];
+    b2s_hash64(h, m);
+    nodes[2 * i] = make_uint4(h[0], h[1], h[2], h[3]);
+    nodes[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// the top of the tree (levels of at most 256 nodes) in one workgroup
+__global__ void __launch_bounds__(256) merkle_top_kernel(uint4* nodes, uint32_t count) {
+    for (uint32_t c = count; c >= 1; c >>= 1) {
+        if (threadIdx.x < c) {
+            const size_t i = (size_t)c + threadIdx.x;
+            // the children were written by other lanes of this workgroup one level ago: volatile loads
+            // so that they are not served from a stale vector-L1 line
+            const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(nodes + 4 * i);
+            uint32_t m[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = src[k];
+            uint32_t h[8];
+            b2s_hash64(h, m);
+            nodes[2 * i] = make_uint4(h[0], h[1], h[2], h[3]);
+            nodes[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+hipError_t launch_merkle_build(uint8_t* nodes, unsigned log_leaves, hipStream_t stream) {
+    size_t count = ((size_t)1 << log_leaves) >> 1;  // nodes on the level above the leaves
+    uint4* n4 = reinterpret_cast<uint4*>(nodes);
+    for (; count > 256; count >>= 1)
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, n4, count);
+    if (count >= 1) hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, n4, (uint32_t)count);
+    return hipGetLastError();
+}
+
 hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
                                 const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,
                                 const uint8_t* roots, const uint32_t* root_ids, size_t n, uint8_t* accept,

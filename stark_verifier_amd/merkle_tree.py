@@ -117,3 +117,17 @@ def get_pseudorandom_indices(seeds, count: int, modulus: int, exclude_multiples_
     ctx.check(ctx.lib.stark_pseudorandom_indices(ctx.handle, s.ctypes.data, s.shape[0], count, modulus,
                                                  exclude_multiples_of or 0, out.ctypes.data))
     return out[0] if single else out
+
+
+def merkle_build(leaves: np.ndarray, ctx: _lib.Context | None = None) -> np.ndarray:
+    """All nodes of the BLAKE2s tree over `leaves` ([L, 32] uint8, L a power of two, already in the tree's
+    leaf order): returns [2L, 32] with the root at [1] and node i = H(node 2i || node 2i+1). Not in the
+    reference (its prover is external); used to build synthetic trees on the device."""
+    ctx = ctx or _lib.default_context()
+    lv = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+    L = lv.shape[0]
+    if L == 0 or L & (L - 1):
+        raise _lib.InvalidArgument(_lib.STARK_ERR_INVALID, f"{L} leaves: not a power of two")
+    nodes = np.zeros((2 * L, 32), dtype=np.uint8)
+    ctx.check(ctx.lib.stark_merkle_build(ctx.handle, lv.ctypes.data, L.bit_length() - 1, nodes.ctypes.data))
+    return nodes

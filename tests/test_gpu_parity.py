@@ -405,3 +405,21 @@ def test_pseudorandom_indices_match_oracle_and_proof(sv, proof_bytes):
     for bad in ((40, 16384, 1), (40, 1, 8), (40, 0, None)):
         with pytest.raises(sv.InvalidArgument):
             sv.merkle_tree.get_pseudorandom_indices(seeds[:2], *bad)
+
+
+@pytest.mark.parametrize("log_leaves", [0, 1, 3, 8, 9, 10, 13, 17])
+def test_merkle_build_matches_oracle(sv, log_leaves):
+    rng = np.random.default_rng(40 + log_leaves)
+    leaves = rng.integers(0, 256, size=(1 << log_leaves, 32), dtype=np.uint8)
+    got = sv.merkle_tree.merkle_build(leaves)
+    exp = oracle.merkle_build(leaves)
+    assert np.array_equal(got[1:], exp[1:])
+    if log_leaves >= 3:
+        # branches cut from the device-built tree verify against its root (permute_4_index leaf order)
+        L = 1 << log_leaves
+        w = log_leaves - 1
+        idx = rng.integers(0, L, size=200, dtype=np.uint32)
+        ld4 = L // 4
+        pos = (idx // ld4 + 4 * (idx % ld4)).astype(np.int64)
+        wit = np.stack([got[((L + pos) >> (k + 1)) ^ 1] for k in range(w)])
+        assert sv.merkle_tree.verify_batch(got[L + pos], got[L + (pos ^ 1)], wit, idx, got[1]).all()

@@ -31,3 +31,18 @@ ctx.synchronize()
 ms = a.elapsed_time(b) / 10
 comp = n * (w + (2 * vs + 63) // 64)
 print("n=%d depth=%d vs=%d  %.3f ms  %.3f G branches/s  %.2f G compressions/s" % (n, depth, vs, ms, n / ms * 1e-6, comp / ms * 1e-6))
+
+# tree build: 2^24 leaves (one compression and 96 bytes per node)
+logL = 24
+L = 1 << logL
+nodes = torch.randint(0, 256, (2 * L, 32), dtype=torch.uint8, device="cuda", generator=g)
+def build():
+    ctx.check(ctx.lib.stark_merkle_build_dev(ctx.handle, nodes.data_ptr(), logL, None))
+build(); ctx.synchronize()
+with torch.cuda.stream(ts):
+    a.record()
+    for _ in range(5): build()
+    b.record()
+ctx.synchronize()
+ms = a.elapsed_time(b) / 5
+print("tree build 2^%d leaves  %.3f ms  %.2f G compressions/s  %.0f GB/s (96 B per node)" % (logL, ms, (L - 1) / ms * 1e-6, 96 * (L - 1) / ms * 1e-6))
