@@ -179,6 +179,23 @@ void free_plan(NttPlan* p) {
     p->table_bytes = 0;
 }
 
+// nine 29-bit limbs of a canonical value
+void to_limbs29(const U256& x, uint32_t out[9]) {
+    for (int i = 0; i < 9; i++) {
+        const unsigned bit = 29u * (unsigned)i, w = bit / 64, sh = bit % 64;
+        uint64_t v = x.w[w] >> sh;
+        if (sh > 35 && w + 1 < 4) v |= x.w[w + 1] << (64 - sh);
+        out[i] = (uint32_t)(v & 0x1FFFFFFFu);
+    }
+}
+
+// the primitive 4th root of unity of a tile whose root of unity is w_t (order 2^log_t >= 4)
+void set_quarter_root(NttPassArgs& a, const U256& w_t, int log_t) {
+    const U256 q = log_t >= 2 ? hostfe::pow_u64(w_t, (uint64_t)1 << (log_t - 2)) : hostfe::from_u64(1);
+    to_limbs29(q, a.iq);
+    to_limbs29(hostfe::mul(q, hostfe::pow_u64(hostfe::from_u64(2), 145)), a.iq2);
+}
+
 // `root` has order exactly 2^log_n (checked by the caller).
 int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, NttPlan** out) {
     std::unique_ptr<NttPlan> plan(new NttPlan);
@@ -236,6 +253,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             return rc;
         }
         a.W = W;
+        set_quarter_root(a, w, (int)log_n);
         plan->passes.push_back(p);
     } else {
         // n = n1 * m, m = n2 (* n3)
@@ -266,6 +284,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             a.load_cfast = a.store_cfast = 1;
             a.canon_in = 1;
             a.W = W1;
+            set_quarter_root(a, w1, l1);
             a.TW = TW1;
             p.tiles = (unsigned)(m >> a.log_c);
             plan->passes.push_back(p);
@@ -297,6 +316,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             a.load_cfast = 0;
             a.store_cfast = 1;
             a.W = W2;
+            set_quarter_root(a, w2, l2);
             p.tiles = (unsigned)(n1 >> a.log_c);
             plan->passes.push_back(p);
         } else {
@@ -329,6 +349,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
                 a.c_limit = ~0ull;
                 a.load_cfast = a.store_cfast = 1;
                 a.W = W2;
+                set_quarter_root(a, w2, l2);
                 a.TW = TW2;
                 p.tiles = (unsigned)(n1 * (n3 >> a.log_c));
                 plan->passes.push_back(p);
@@ -355,6 +376,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
                 a.load_cfast = 0;
                 a.store_cfast = 1;
                 a.W = W3;
+                set_quarter_root(a, w3, l3);
                 p.tiles = (unsigned)((n1 >> a.log_c) * n2);
                 plan->passes.push_back(p);
             }

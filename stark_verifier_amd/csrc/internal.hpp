@@ -24,6 +24,8 @@ struct NttPassArgs {
     const uint32_t* in;
     uint32_t* out;
     const uint32_t* W;   // [2^log_t] powers of the tile's root of unity
+    uint32_t iq[9];      // 29-bit limbs of W[2^log_t / 4], the primitive 4th root of unity every butterfly multiplies by
+    uint32_t iq2[9];     // ... and of that root times 2^145 mod p (split multiplication)
     const uint32_t* TW;  // inter-pass twiddles (scaled by n^-1 for the inverse), or null
     uint64_t poly_stride;
     uint64_t inA, inB, inC, inS;

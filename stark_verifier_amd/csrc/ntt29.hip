@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
                 t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
             }
-            F29 a3 = f29_mul(f29_sub(x1, x3), f29_load_raw(a.W + 12 * (size_t)Q));
+            F29 a3 = f29_mul_uniform2(f29_sub(x1, x3), a.iq, a.iq2);
             y1 = f29_add(a1, a3);
             y3 = f29_sub(a1, a3);
             if (tw_on) {
