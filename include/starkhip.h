@@ -201,6 +201,43 @@ int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_
                             const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
                             size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status);
 
+/* The same with one (input, output) pair per proof: inputs and outputs are n_proofs x 8 limbs, proof i is checked
+ * as verify_mimc_proof(inputs[i], num_steps, round_constants, outputs[i], proof_i, p). */
+int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                               const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
+                               size_t n_constants, const uint32_t* outputs, uint8_t* accept, uint8_t* status);
+
+/* ---------------------------------------------------------------------------------------
+ * Proof generation — no counterpart in the reference: its proofs come from an external program
+ * (README.md:9). Makes the proofs verify_mimc_proof (src/lib.rs:99-197) accepts, in the wire format
+ * deserializer::from_bytes reads (src/deserializer.rs:16-140), many at a time and entirely on the device:
+ * MiMC trace, the P / D / B columns over the 8x extended domain, their Merkle tree, the linear
+ * combination L with its tree, the FRI layers with theirs, the sampled branches. With input 3,
+ * num_steps 8192 and the 64 constants of src/main.rs:209-212 the output equals the reference's proof.bin.
+ * ------------------------------------------------------------------------------------- */
+
+/* Bytes of one serialized proof for these parameters (566,508 for 8192 steps); 0 if they are rejected:
+ * num_steps a power of two in [16, 2^17], n_constants a power of two <= num_steps. */
+size_t stark_mimc_proof_size(uint64_t num_steps, size_t n_constants);
+
+/*
+ * inputs: n x 8 limbs (any 256-bit values); round_constants: n_constants x 8 limbs (host memory).
+ * proofs: n x stark_mimc_proof_size() bytes out, proof i at proofs + i * size; outputs: n x 8 limbs, the
+ * last trace value mimc(input) (src/utils.rs:8-16) the verifier is called with.
+ * Tables that depend on (num_steps, round_constants) are built on first use and kept in the context (one
+ * parameter set at a time). Proofs are made in chunks sized by STARKHIP_PROVER_MB (default 16384 MiB of
+ * device memory, about 17 MiB per proof at 8192 steps).
+ */
+int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, size_t n, uint64_t num_steps,
+                           const uint32_t* round_constants, size_t n_constants, uint8_t* proofs, uint32_t* outputs);
+
+/* Device version: d_inputs, d_proofs (proof i at d_proofs + i * proof_stride; proof_stride a multiple of 4, at
+ * least the proof size), d_outputs are device pointers, 16-byte aligned; round_constants stays a host pointer.
+ * Queued on `stream` (NULL = the context's stream); does not synchronise. */
+int stark_mimc_prove_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, uint64_t num_steps,
+                               const uint32_t* round_constants, size_t n_constants, void* d_proofs,
+                               uint64_t proof_stride, void* d_outputs, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Test and benchmark support (no counterpart in the reference).
  * ------------------------------------------------------------------------------------- */

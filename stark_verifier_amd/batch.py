@@ -34,6 +34,30 @@ def verify_mimc_batch(proofs: Sequence[bytes], inp: int, num_steps: int, round_c
     return accept, status
 
 
+def verify_mimc_batch_io(proofs: Sequence[bytes], inputs: Sequence[int], num_steps: int, round_constants: Sequence[int],
+                         outputs: Sequence[int], ctx: _lib.Context | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """verify_mimc_batch with one (input, output) pair per proof: proof i is checked as the reference's
+    verify_mimc_proof(inputs[i], num_steps, round_constants, outputs[i], proof_i, p)."""
+    ctx = ctx or _lib.default_context()
+    n = len(proofs)
+    if len(inputs) != n or len(outputs) != n:
+        raise _lib.InvalidArgument(_lib.STARK_ERR_INVALID, "one input and one output per proof")
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(p) for p in proofs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(proofs), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    rc = np.ascontiguousarray(np.concatenate([_limbs(c % MODULUS) for c in round_constants]) if len(round_constants)
+                              else np.zeros(0, dtype=np.uint32))
+    i = np.ascontiguousarray(np.concatenate([_limbs(int(x) % MODULUS) for x in inputs])) if n else np.zeros(8, dtype=np.uint32)
+    o = np.ascontiguousarray(np.concatenate([_limbs(int(x) % MODULUS) for x in outputs])) if n else np.zeros(8, dtype=np.uint32)
+    accept = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.uint8)
+    ctx.check(ctx.lib.stark_mimc_verify_batch_io(ctx.handle, blob.ctypes.data if n else None, offsets.ctypes.data, n,
+                                                 i.ctypes.data, num_steps, rc.ctypes.data if rc.size else None,
+                                                 len(round_constants), o.ctypes.data, accept.ctypes.data if n else None,
+                                                 status.ctypes.data if n else None))
+    return accept, status
+
+
 def verify_mimc_batch_sharded(proofs: Sequence[bytes], inp: int, num_steps: int, round_constants: Sequence[int], output: int,
                               ctx: _lib.Context | None = None, verify=None):
     """The same batch split over the ranks of the default process group (one process per GPU): proofs are

@@ -191,7 +191,12 @@ enum Status : uint8_t {
 };
 
 struct Params {
-    U256 inp, output;
+    // input / output of the MiMC instance of proof i: one pair for all (io_stride 0) or one per proof (8)
+    const uint32_t *inputs, *outputs;
+    size_t io_stride;
+    U256 inp(size_t i) const { return hostfe::canon(hostfe::from_limbs(inputs + io_stride * i)); }
+    U256 output(size_t i) const { return hostfe::canon(hostfe::from_limbs(outputs + io_stride * i)); }
+    U256 inv_last_m1;  // 1 / (last_step - 1)
     uint64_t num_steps;
     std::vector<U256> mini_poly;  // fft_inv(round_constants, val): computed once per call on the device
     U256 g2, last_step;
@@ -289,7 +294,7 @@ static void interp_4(const U256 xs[4], const U256 ys[4], U256 out[4]) {
 }
 
 // The scalar checks of lib.rs:31-97 and :161-192 on a proof whose branches all matched.
-static uint8_t field_checks(const ProofWork& pw, const Params& P) {
+static uint8_t field_checks(const ProofWork& pw, const Params& P, size_t gi) {
     const Proof& pr = pw.proof;
     U256 rou = P.g2;
     uint64_t rou_deg = P.precision;
@@ -324,7 +329,8 @@ static uint8_t field_checks(const ProofWork& pw, const Params& P) {
         k[i] = from_be(d);
     }
     const U256 one = hostfe::from_u64(1);
-    const U256 slope = fe_mul(fe_sub(P.output, P.inp), hostfe::inverse(fe_sub(P.last_step, one)));
+    const U256 inp = P.inp(gi);
+    const U256 slope = fe_mul(fe_sub(P.output(gi), inp), P.inv_last_m1);
     for (size_t i = 0; i < pw.positions.size(); i++) {
         const U256 x = hostfe::pow_u64(P.g2, pw.positions[i]);
         const U256 x_steps = hostfe::pow_u64(x, P.num_steps);
@@ -341,7 +347,7 @@ static uint8_t field_checks(const ProofWork& pw, const Params& P) {
         }
         const U256 p3 = fe_mul(fe_mul(p_of_x, p_of_x), p_of_x);
         if (!is_zero(fe_sub(fe_sub(fe_sub(p_of_g1x, p3), kx), fe_mul(z, d_of_x)))) return ST_TRANSITION;
-        const U256 interp = fe_add(P.inp, fe_mul(slope, fe_sub(x, one)));
+        const U256 interp = fe_add(inp, fe_mul(slope, fe_sub(x, one)));
         const U256 zero2 = fe_mul(fe_sub(x, one), fe_sub(x, P.last_step));
         if (!is_zero(fe_sub(fe_sub(p_of_x, fe_mul(b_of_x, zero2)), interp))) return ST_BOUNDARY;
         U256 lc = fe_sub(l_of_x, d_of_x);
@@ -370,13 +376,13 @@ static void parallel_for(size_t n, unsigned threads, F f) {
 }
 
 // The same checks on the device: one lane per (proof, layer, sample) and per (proof, position).
-static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, const Params& P, const CheckParams& CP,
-                               const uint32_t* d_mini, unsigned threads) {
+static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, size_t first, const Params& P,
+                               const CheckParams& CP, const uint32_t* d_mini, unsigned threads) {
     const size_t m = work.size();
     std::vector<size_t> fri_off(m + 1, 0), con_off(m + 1, 0);
     for (size_t i = 0; i < m; i++) {
         size_t f = 0, c = 0;
-        if (work[i].status == ST_ACCEPT && !work[i].plain_values) work[i].status = field_checks(work[i], P);  // rare: host path
+        if (work[i].status == ST_ACCEPT && !work[i].plain_values) work[i].status = field_checks(work[i], P, first + i);  // rare: host path
         else if (work[i].status == ST_ACCEPT) {
             for (auto& ys : work[i].ys) f += ys.size();
             c = work[i].positions.size();
@@ -388,7 +394,7 @@ static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, con
     if (nf + nc == 0) return STARK_OK;
     std::vector<FriLane> fri(nf);
     std::vector<ConstraintLane> con(nc);
-    std::vector<uint8_t> kk(128 * m, 0);
+    std::vector<uint8_t> kk(CHECK_PROOF_BYTES * m, 0);  // per proof: k1..k4, input, slope
     parallel_for(m, threads, [&](size_t i) {
         ProofWork& pw = work[i];
         if (pw.status != ST_ACCEPT || !pw.plain_values) return;
@@ -412,7 +418,14 @@ static int device_field_checks(stark_ctx* ctx, std::vector<ProofWork>& work, con
             uint8_t msg[33];
             memcpy(msg, pr.merkle_root, 32);
             msg[32] = (uint8_t)(k + 1);
-            hostb2s::hash(msg, 33, &kk[128 * i + 32 * k]);
+            hostb2s::hash(msg, 33, &kk[CHECK_PROOF_BYTES * i + 32 * k]);
+        }
+        {
+            const U256 inp = P.inp(first + i);
+            uint32_t l[16];
+            hostfe::to_limbs(inp, l);
+            hostfe::to_limbs(fe_mul(fe_sub(P.output(first + i), inp), P.inv_last_m1), l + 8);
+            memcpy(&kk[CHECK_PROOF_BYTES * i + 128], l, 64);
         }
         o = con_off[i];
         for (size_t k = 0; k < pw.positions.size(); k++, o++) {
@@ -466,12 +479,12 @@ using namespace starkhip::batch;
     catch (...) { return STARK_ERR_HIP; }
 
 
-extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
-                                       const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
-                                       size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) try {
+static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs, const uint32_t* inp,
+                       const uint32_t* output, size_t io_stride, uint64_t num_steps, const uint32_t* round_constants,
+                       size_t n_constants, uint8_t* accept, uint8_t* status) {
     if (!ctx) return STARK_ERR_INVALID;
     if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
-    if (!inp || !output || (n_constants && !round_constants)) return STARK_ERR_INVALID;
+    if (((n_proofs || !io_stride) && (!inp || !output)) || (n_constants && !round_constants)) return STARK_ERR_INVALID;
     for (size_t i = 0; i < n_proofs; i++)
         if (offsets[i + 1] < offsets[i]) return STARK_ERR_INVALID;
     auto set_all = [&](uint8_t st) {
@@ -485,8 +498,9 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
     auto pow2 = [](uint64_t x) { return x && !(x & (x - 1)); };
     if (num_steps > (1ull << 32) / 8 || !pow2(num_steps) || !pow2(n_constants) || n_constants > num_steps) return set_all(ST_PARAMS);
     Params P;
-    P.inp = hostfe::canon(hostfe::from_limbs(inp));
-    P.output = hostfe::canon(hostfe::from_limbs(output));
+    P.inputs = inp;
+    P.outputs = output;
+    P.io_stride = io_stride;
     P.num_steps = num_steps;
     P.precision = num_steps * 8;
     P.skips = 8;
@@ -504,6 +518,7 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         P.g2 = hostfe::pow_u256(hostfe::from_u64(7), q);
     }
     P.last_step = hostfe::pow_u64(P.g2, (num_steps - 1) * P.skips);
+    P.inv_last_m1 = hostfe::inverse(fe_sub(P.last_step, hostfe::from_u64(1)));
     {
         // constants_mini_polynomial = fft_inv(round_constants, val) (lib.rs:118,125): on the device
         const U256 val = hostfe::pow_u64(P.g2, 8 * P.skips2);
@@ -526,13 +541,9 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
     CheckParams CP;
     uint32_t* d_mini = nullptr;
     {
-        const U256 one = hostfe::from_u64(1);
-        const U256 slope = fe_mul(fe_sub(P.output, P.inp), hostfe::inverse(fe_sub(P.last_step, one)));
         hostfe::to_limbs(P.g2, CP.g2);
         hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
         hostfe::to_limbs(P.last_step, CP.last_step);
-        hostfe::to_limbs(P.inp, CP.inp);
-        hostfe::to_limbs(slope, CP.slope);
         CP.precision = (uint32_t)P.precision;
         CP.log_steps = CP.log_skips2 = 0;
         while ((1ull << CP.log_steps) < P.num_steps) CP.log_steps++;
@@ -709,10 +720,10 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         if (field_on_host) {
             parallel_for(m, threads, [&](size_t i) {
                 ProofWork& pw = work[i];
-                if (pw.status == ST_ACCEPT) pw.status = field_checks(pw, P);
+                if (pw.status == ST_ACCEPT) pw.status = field_checks(pw, P, c0 + i);
             });
         } else {
-            int rc = device_field_checks(ctx, work, P, CP, d_mini, threads);
+            int rc = device_field_checks(ctx, work, c0, P, CP, d_mini, threads);
             if (rc != STARK_OK) {
                 (void)hipFree(d_mini);
                 return rc;
@@ -730,4 +741,16 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
         fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
                 n_proofs, t_parse, t_bucket, t_flatten, t_merkle, t_field);
     return STARK_OK;
+}
+
+extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                                       const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
+                                       size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) try {
+    return verify_impl(ctx, proofs, offsets, n_proofs, inp, output, 0, num_steps, round_constants, n_constants, accept, status);
+} STARK_CATCH
+
+extern "C" int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                                          const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
+                                          size_t n_constants, const uint32_t* outputs, uint8_t* accept, uint8_t* status) try {
+    return verify_impl(ctx, proofs, offsets, n_proofs, inputs, outputs, 8, num_steps, round_constants, n_constants, accept, status);
 } STARK_CATCH

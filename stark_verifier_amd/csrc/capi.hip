@@ -55,7 +55,20 @@ struct stark_ctx {
     size_t chunk_bytes = (size_t)2048 << 20;  // input bytes transformed per group of pass launches (scratch = 1.5x)
     size_t table_budget = (size_t)8 << 30;   // twiddle tables kept across calls (STARKHIP_TABLE_MB)
     uint64_t use_counter = 0;
+    std::unique_ptr<CtxAttachment> attach[CTX_SLOTS];
 };
+
+namespace starkhip {
+CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot) {
+    return ctx && slot >= 0 && slot < CTX_SLOTS ? ctx->attach[slot].get() : nullptr;
+}
+void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a) {
+    if (ctx && slot >= 0 && slot < CTX_SLOTS) ctx->attach[slot].reset(a);
+}
+void ctx_set_error(stark_ctx* ctx, const char* text) {
+    if (ctx) ctx->err = text ? text : "";
+}
+}  // namespace starkhip
 
 namespace {
 
@@ -532,6 +545,7 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& a : ctx->attach) a.reset();
     for (auto& p : ctx->plans) free_plan(p.get());
     for (auto& p : ctx->shard_tables) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -142,12 +142,13 @@ __global__ void __launch_bounds__(256) constraint_check_kernel(const ConstraintL
     // boundary (:184-187): p - b * (x-1)(x-last) - (inp + slope*(x-1)) == 0
     if (!st) {
         const F29 zero2 = mul_t(x_1, x_last);
-        const F29 interp = add_t(load_limbs(P.inp), mul_t(x_1, load_limbs(P.slope)));
+        const uint32_t* io = reinterpret_cast<const uint32_t*>(kk + CHECK_PROOF_BYTES * (size_t)L.proof + 128);
+        const F29 interp = add_t(load_limbs(io), mul_t(x_1, load_limbs(io + 8)));
         if (!is_zero_t(sub_t(sub_t(p, mul_t(zero2, b)), interp))) st = 7;
     }
     // linear combination (:190)
     if (!st) {
-        const uint8_t* k = kk + 128 * (size_t)L.proof;
+        const uint8_t* k = kk + CHECK_PROOF_BYTES * (size_t)L.proof;
         const F29 k1 = load_be(k), k2 = load_be(k + 32), k3 = load_be(k + 64), k4 = load_be(k + 96);
         F29 acc = sub_t(l, d);
         acc = sub_t(acc, mul_t(k1, p));

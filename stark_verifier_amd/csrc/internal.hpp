@@ -4,7 +4,20 @@
 #include <stddef.h>
 #include <stdint.h>
 
+struct stark_ctx;
+
 namespace starkhip {
+
+// ---- capi.hip: state other translation units keep on a context ----
+// An attachment lives in a numbered slot of the context and is destroyed with it (after the stream has
+// drained), or when the slot is set again.
+struct CtxAttachment {
+    virtual ~CtxAttachment() {}
+};
+constexpr int CTX_SLOTS = 4;
+CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot);
+void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a);
+void ctx_set_error(stark_ctx* ctx, const char* text);
 
 // ---- merkle.hip ----
 hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
@@ -89,11 +102,14 @@ struct alignas(16) ConstraintLane {
     uint32_t pad[2];
 };
 struct CheckParams {
-    uint32_t g2[8], q4[8], last_step[8], inp[8], slope[8];  // canonical limbs
+    uint32_t g2[8], q4[8], last_step[8];  // canonical limbs
     uint32_t precision, log_steps, log_skips2, n_coeffs;
 };
 hipError_t launch_fri_check(const FriLane* lanes, size_t n, const CheckParams& P, uint8_t* status, hipStream_t stream);
-// kk: per proof 4 x 32 bytes BLAKE2s(merkle_root || {1,2,3,4}); mini_poly: n_coeffs x 8 canonical limbs
+// kk: per proof CHECK_PROOF_BYTES: 4 x 32 bytes BLAKE2s(merkle_root || {1,2,3,4}), then 8 + 8 canonical limbs: the
+// instance's input and the slope (output - input) / (last_step - 1) of its boundary interpolant;
+// mini_poly: n_coeffs x 8 canonical limbs
+constexpr size_t CHECK_PROOF_BYTES = 192;
 hipError_t launch_constraint_check(const ConstraintLane* lanes, size_t n, const CheckParams& P, const uint8_t* kk,
                                    const uint32_t* mini_poly, uint8_t* status, hipStream_t stream);
 

@@ -1,0 +1,38 @@
+"""Host mirror of the proof generator: MiMC STARK proofs in the reference's wire format
+(src/deserializer.rs:16-140), made on the GPU many at a time.  The reference itself only verifies;
+its proofs come from an external program (README.md:9)."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .fft import MODULUS, _limbs
+
+
+def mimc_proof_size(num_steps: int, n_constants: int) -> int:
+    """Bytes of one serialized proof, 0 when the parameters are rejected."""
+    return int(_lib.load().stark_mimc_proof_size(num_steps, n_constants))
+
+
+def mk_mimc_proofs(inputs: Sequence[int], num_steps: int, round_constants: Sequence[int],
+                   ctx: _lib.Context | None = None) -> Tuple[List[bytes], List[int]]:
+    """One proof per input: returns (proofs, outputs) with outputs[i] = mimc(inputs[i], num_steps,
+    round_constants) (reference src/utils.rs:8-16), the value verify_mimc_proof is called with."""
+    ctx = ctx or _lib.default_context()
+    n = len(inputs)
+    size = mimc_proof_size(num_steps, len(round_constants))
+    if size == 0:
+        raise _lib.InvalidArgument(_lib.STARK_ERR_INVALID, "num_steps / round_constants rejected")
+    if n == 0:
+        return [], []
+    inp = np.ascontiguousarray(np.concatenate([_limbs(int(x) % (1 << 256)) for x in inputs]))
+    rc = np.ascontiguousarray(np.concatenate([_limbs(int(c) % MODULUS) for c in round_constants]))
+    proofs = np.empty(n * size, dtype=np.uint8)
+    outputs = np.empty(n * 8, dtype=np.uint32)
+    ctx.check(ctx.lib.stark_mimc_prove_batch(ctx.handle, inp.ctypes.data, n, num_steps, rc.ctypes.data,
+                                             len(round_constants), proofs.ctypes.data, outputs.ctypes.data))
+    blob = proofs.tobytes()
+    outs = [int.from_bytes(outputs[8 * i:8 * i + 8].astype("<u4").tobytes(), "little") for i in range(n)]
+    return [blob[i * size:(i + 1) * size] for i in range(n)], outs
