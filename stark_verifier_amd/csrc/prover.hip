@@ -88,7 +88,8 @@ __device__ __forceinline__ F29 limbs_arg(const uint32_t (&l)[8]) {
 // ---- trace: lane = proof ----
 __global__ void __launch_bounds__(64)
 trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, const uint32_t* __restrict__ consts,
-             uint32_t cmask, uint32_t* __restrict__ trace, uint32_t* __restrict__ outputs, Dev D) {
+             uint32_t cmask, uint32_t* __restrict__ trace, uint32_t* __restrict__ outputs, uint32_t* __restrict__ io,
+             Dev D) {
     const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= n) return;
     F29 x = norm(load_limbs(inputs + 8 * (size_t)pr));
@@ -102,8 +103,8 @@ trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, co
     }
     store_limbs(row + 8 * (size_t)(steps - 1), x);
     store_limbs(outputs + 8 * (size_t)pr, x);
-    store_limbs(D.io + 16 * (size_t)pr, inp);
-    store_limbs(D.io + 16 * (size_t)pr + 8, mul_t(f29_sub(x, inp), limbs_arg(D.inv_last_m1)));
+    store_limbs(io + 16 * (size_t)pr, inp);
+    store_limbs(io + 16 * (size_t)pr + 8, mul_t(f29_sub(x, inp), limbs_arg(D.inv_last_m1)));
 }
 
 // ---- D, B and the 96-byte leaves: lane = (proof, point) ----
@@ -118,10 +119,10 @@ __global__ void __launch_bounds__(256) columns_kernel(Dev D) {
     const F29 inp = load_limbs(D.io + 16 * (size_t)pr), slope = load_limbs(D.io + 16 * (size_t)pr + 8);
     // d = (p(g1 x) - p^3 - k) * (x - last) / (x^steps - 1)
     const F29 p3 = mul_t(mul_t(p, p), p);
-    const F29 d = mul_t(sub_t(sub_t(pg, p3), k), load_limbs(D.zfac + 8 * (size_t)i));
-    // b = (p - interpolant) / ((x - 1)(x - last)), interpolant = inp + slope * (x - 1)
-    const F29 interp = add_t(inp, mul_t(f29_sub(x, one()), slope));
-    const F29 b = mul_t(f29_sub(p, interp), load_limbs(D.invz2 + 8 * (size_t)i));
+    const F29 d = mul_t(f29_sub(f29_sub(pg, p3), k), load_limbs(D.zfac + 8 * (size_t)i));
+    // b = (p - interpolant) / ((x - 1)(x - last)), interpolant = inp + slope * (x - 1) (a sum of two tight values)
+    const F29 interp = f29_add(inp, mul_t(f29_sub(x, one()), slope));
+    const F29 b = mul_t(f29_sub2(p, interp), load_limbs(D.invz2 + 8 * (size_t)i));
     uint8_t* leaf = D.leaves + 96 * (((size_t)pr << D.log_n) + perm4(i, D.log_n));
     store_be(leaf, p);
     store_be(leaf + 32, d);
@@ -454,6 +455,9 @@ struct Plan : CtxAttachment {
     // chunk buffers, grown on demand
     uint8_t* work = nullptr;
     size_t work_bytes = 0;
+    // traces of a whole group of chunks ([group][steps][8]) followed by their [group][16] input / slope pairs
+    uint8_t* traces = nullptr;
+    size_t traces_bytes = 0;
     ~Plan() override {
         (void)hipFree(d_xs);
         (void)hipFree(d_zfac);
@@ -462,6 +466,7 @@ struct Plan : CtxAttachment {
         (void)hipFree(d_consts);
         (void)hipFree(d_items);
         (void)hipFree(work);
+        (void)hipFree(traces);
     }
 };
 
@@ -577,7 +582,7 @@ static int get_plan(stark_ctx* ctx, uint64_t steps, const uint32_t* round_consta
 // Device bytes one proof of a chunk needs, apart from its output.
 static size_t per_proof_bytes(const Layout& L) {
     const size_t N = (size_t)1 << L.log_n;
-    size_t b = N * 32 /*P*/ + N * 96 /*leaves*/ + N * 32 /*trace tree*/ + 64 /*io*/ + 512 /*coef*/ + 32 /*troot*/;
+    size_t b = N * 32 /*P*/ + N * 96 /*leaves*/ + N * 32 /*trace tree*/ + 512 /*coef*/ + 32 /*troot*/;
     for (unsigned k = 0; k <= L.nl; k++) b += (N >> (2 * k)) * 64 + 32;
     b += 4 * (FRI_SAMPLES * L.nl + SPOT_CHECKS);
     return b;
@@ -594,9 +599,31 @@ static int build_trees_level(stark_ctx* ctx, uint8_t* nodes, size_t stride_bytes
     return STARK_OK;
 }
 
-// One chunk: d_inputs [B][8] -> d_proofs (B x out_stride bytes), d_outputs [B][8]; everything queued on st.
-static int prove_chunk(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, uint32_t B, uint8_t* d_proofs, uint64_t out_stride,
-                       uint32_t* d_outputs, hipStream_t st) {
+// The sequential part for a whole group of proofs at once: a lane per proof, so the time does not depend on the
+// group's size until the chip is full. d_inputs [G][8] -> traces [G][steps][8], io [G][16], d_outputs [G][8].
+static int trace_group(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, size_t G, uint32_t* d_outputs, hipStream_t st) {
+    const size_t steps = (size_t)pl.steps, need = G * steps * 32 + G * 64;
+    if (need > pl.traces_bytes) {
+        P_TRY(hipStreamSynchronize(st));
+        if (pl.traces) P_TRY(hipFree(pl.traces));
+        pl.traces = nullptr;
+        pl.traces_bytes = 0;
+        P_TRY(hipMalloc((void**)&pl.traces, need));
+        pl.traces_bytes = need;
+    }
+    Dev D = {};
+    memcpy(D.inv_last_m1, pl.inv_last_m1, 32);
+    hipLaunchKernelGGL(trace_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, st, d_inputs, (uint32_t)G, (uint32_t)steps,
+                       pl.d_consts, (uint32_t)(pl.consts.size() / 8 - 1), (uint32_t*)pl.traces, d_outputs,
+                       (uint32_t*)(pl.traces + G * steps * 32), D);
+    P_TRY(hipGetLastError());
+    return STARK_OK;
+}
+
+// One chunk of a traced group: d_trace [B][steps][8] (transformed in place), d_io [B][16] -> d_proofs (B x out_stride
+// bytes); everything queued on st.
+static int prove_chunk(stark_ctx* ctx, Plan& pl, uint32_t* d_trace, uint32_t* d_io, uint32_t B, uint8_t* d_proofs,
+                       uint64_t out_stride, hipStream_t st) {
     const Layout& L = pl.lay;
     const uint32_t N = 1u << L.log_n, steps = (uint32_t)pl.steps;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -608,7 +635,7 @@ static int prove_chunk(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, uint3
         return at;
     };
     const size_t o_P = take((size_t)B * N * 32), o_leaves = take((size_t)B * N * 96), o_tn = take((size_t)B * N * 32),
-                 o_io = take((size_t)B * 64), o_coef = take((size_t)B * 512), o_troot = take((size_t)B * 32);
+                 o_coef = take((size_t)B * 512), o_troot = take((size_t)B * 32);
     size_t o_tree[MAX_TREES], o_root[MAX_TREES];
     for (unsigned k = 0; k <= L.nl; k++) {
         o_tree[k] = take((size_t)B * (N >> (2 * k)) * 64);
@@ -634,7 +661,7 @@ static int prove_chunk(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, uint3
     D.invz2 = pl.d_invz2;
     D.kext = pl.d_kext;
     D.P = (uint32_t*)(pl.work + o_P);
-    D.io = (uint32_t*)(pl.work + o_io);
+    D.io = d_io;
     D.coef = (uint32_t*)(pl.work + o_coef);
     D.leaves = pl.work + o_leaves;
     D.tnodes = pl.work + o_tn;
@@ -648,11 +675,7 @@ static int prove_chunk(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, uint3
     memcpy(D.q4, pl.q4, 32);
     memcpy(D.inv_last_m1, pl.inv_last_m1, 32);
 
-    // trace (compact rows, in the leaves area which is free until the columns are written), inverse transform
-    uint32_t* d_trace = (uint32_t*)D.leaves;
-    hipLaunchKernelGGL(trace_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_inputs, B, steps, pl.d_consts,
-                       (uint32_t)(pl.consts.size() / 8 - 1), d_trace, d_outputs, D);
-    P_TRY(hipGetLastError());
+    // trace polynomial: inverse transform of the trace rows
     int rc = stark_ntt_batch_dev(ctx, d_trace, d_trace, L.log_steps, B, pl.g1l, 1, st);
     if (rc != STARK_OK) return rc;
     // zero-extend to N coefficients, evaluate over the extended domain
@@ -696,6 +719,32 @@ static size_t chunk_proofs(const Layout& L, size_t n) {
     return B < n ? B : n;
 }
 
+// Groups of proofs (at most 4 GiB of traces) are traced together, then finished in chunks of at most B.
+// out_for(first, m) names the device buffer chunk [first, first + m) is written to; done(first, m) runs after the
+// chunk has been queued.
+template <class OutFn, class DoneFn>
+static int prove_all(stark_ctx* ctx, Plan& pl, const uint32_t* d_inputs, size_t n, uint32_t* d_outputs, size_t B,
+                     uint64_t out_stride, hipStream_t st, OutFn out_for, DoneFn done) {
+    const size_t steps = (size_t)pl.steps;
+    size_t G = ((size_t)4 << 30) / (steps * 32);
+    if (G > n) G = n;
+    for (size_t g0 = 0; g0 < n; g0 += G) {
+        const size_t g = n - g0 < G ? n - g0 : G;
+        int rc = trace_group(ctx, pl, d_inputs + 8 * g0, g, d_outputs + 8 * g0, st);
+        if (rc != STARK_OK) return rc;
+        uint32_t* io = (uint32_t*)(pl.traces + g * steps * 32);
+        for (size_t c0 = 0; c0 < g; c0 += B) {
+            const size_t m = g - c0 < B ? g - c0 : B;
+            rc = prove_chunk(ctx, pl, (uint32_t*)pl.traces + c0 * steps * 8, io + 16 * c0, (uint32_t)m, out_for(g0 + c0, m),
+                             out_stride, st);
+            if (rc == STARK_OK) rc = done(g0 + c0, m);
+            if (rc != STARK_OK) return rc;
+        }
+    }
+    return STARK_OK;
+}
+
+
 }  // namespace prover
 }  // namespace starkhip
 
@@ -734,14 +783,9 @@ extern "C" int stark_mimc_prove_batch_dev(stark_ctx* ctx, const void* d_inputs, 
         return STARK_ERR_INVALID;
     }
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)stark_ctx_stream(ctx);
-    const size_t B = chunk_proofs(pl->lay, n);
-    for (size_t c0 = 0; c0 < n; c0 += B) {
-        const size_t m = n - c0 < B ? n - c0 : B;
-        rc = prove_chunk(ctx, *pl, (const uint32_t*)d_inputs + 8 * c0, (uint32_t)m, (uint8_t*)d_proofs + proof_stride * c0,
-                         proof_stride, (uint32_t*)d_outputs + 8 * c0, st);
-        if (rc != STARK_OK) return rc;
-    }
-    return STARK_OK;
+    uint8_t* out = (uint8_t*)d_proofs;
+    return prove_all(ctx, *pl, (const uint32_t*)d_inputs, n, (uint32_t*)d_outputs, chunk_proofs(pl->lay, n), proof_stride, st,
+                     [&](size_t first, size_t) { return out + proof_stride * first; }, [](size_t, size_t) { return STARK_OK; });
 } STARK_CATCH
 
 extern "C" int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, size_t n, uint64_t num_steps,
@@ -756,29 +800,65 @@ extern "C" int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, si
     Plan* pl;
     int rc = get_plan(ctx, num_steps, round_constants, n_constants, &pl);
     if (rc != STARK_OK) return rc;
+    if (n == 0) return STARK_OK;
     const size_t psz = pl->lay.proof_size;
     hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
-    const size_t B = chunk_proofs(pl->lay, n);
-    uint8_t* d = nullptr;
-    const size_t o_out = (B * 32 + 255) & ~(size_t)255, o_pr = 2 * o_out;
-    if (n == 0) return STARK_OK;
-    P_TRY(hipMalloc((void**)&d, o_pr + B * psz));
-    for (size_t c0 = 0; c0 < n && rc == STARK_OK; c0 += B) {
-        const size_t m = n - c0 < B ? n - c0 : B;
-        hipError_t e = hipMemcpyAsync(d, inputs + 8 * c0, m * 32, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            rc = prove_chunk(ctx, *pl, (const uint32_t*)d, (uint32_t)m, d + o_pr, psz, (uint32_t*)(d + o_out), st);
-            if (rc != STARK_OK) break;
-            e = hipMemcpyAsync(outputs + 8 * c0, d + o_out, m * 32, hipMemcpyDeviceToHost, st);
+    // small chunks, two output buffers: the copy of one chunk to the host runs while the next is computed
+    size_t B = chunk_proofs(pl->lay, n);
+    if (B > 256) B = 256;
+    struct Res {
+        uint8_t* d = nullptr;
+        hipStream_t cs = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Res() {
+            if (cs) (void)hipStreamSynchronize(cs);
+            (void)hipFree(d);
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+            if (cs) (void)hipStreamDestroy(cs);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(proofs + psz * c0, d + o_pr, m * psz, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) {
-            ctx_set_error(ctx, hipGetErrorString(e));
-            rc = STARK_ERR_HIP;
-        }
+    } R;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_out = up(n * 32), o_b0 = 2 * o_out, o_b1 = o_b0 + up(B * psz);
+    P_TRY(hipMalloc((void**)&R.d, o_b1 + up(B * psz)));
+    P_TRY(hipStreamCreateWithFlags(&R.cs, hipStreamNonBlocking));
+    for (hipEvent_t& e : R.ev) P_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    P_TRY(hipMemcpyAsync(R.d, inputs, n * 32, hipMemcpyHostToDevice, st));
+    uint8_t* bufs[2] = {R.d + o_b0, R.d + o_b1};
+    struct Pending {
+        size_t first = 0, m = 0;
+        int buf = 0;
+        bool valid = false;
+    } prev;
+    auto flush = [&](Pending& p) -> int {
+        if (!p.valid) return STARK_OK;
+        p.valid = false;
+        P_TRY(hipStreamWaitEvent(R.cs, R.ev[p.buf], 0));
+        P_TRY(hipMemcpyAsync(proofs + psz * p.first, bufs[p.buf], p.m * psz, hipMemcpyDeviceToHost, R.cs));
+        P_TRY(hipStreamSynchronize(R.cs));
+        return STARK_OK;
+    };
+    size_t k = 0;
+    rc = prove_all(ctx, *pl, (const uint32_t*)R.d, n, (uint32_t*)(R.d + o_out), B, psz, st,
+                   [&](size_t, size_t) { return bufs[k & 1]; },
+                   [&](size_t first, size_t m) -> int {
+                       P_TRY(hipEventRecord(R.ev[k & 1], st));
+                       Pending cur;
+                       cur.first = first;
+                       cur.m = m;
+                       cur.buf = (int)(k & 1);
+                       cur.valid = true;
+                       k++;
+                       const int r = flush(prev);  // the previous chunk goes out while this one is computed
+                       prev = cur;
+                       return r;
+                   });
+    if (rc == STARK_OK) rc = flush(prev);
+    if (rc != STARK_OK) {
+        (void)hipStreamSynchronize(st);
+        return rc;
     }
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(d);
-    return rc;
+    P_TRY(hipMemcpyAsync(outputs, R.d + o_out, n * 32, hipMemcpyDeviceToHost, st));
+    P_TRY(hipStreamSynchronize(st));
+    return STARK_OK;
 } STARK_CATCH
