@@ -157,4 +157,42 @@ inline std::vector<bool> verify_mimc_proofs(Context& c, const U256& inp, size_t 
     return std::vector<bool>(accept.begin(), accept.end());
 }
 
+// The same with one (input, output) pair per proof.
+inline std::vector<bool> verify_mimc_proofs(Context& c, const std::vector<U256>& inputs, size_t num_steps,
+                                            const std::vector<U256>& round_constants, const std::vector<U256>& outputs,
+                                            const std::vector<std::vector<uint8_t>>& proofs, std::vector<uint8_t>* status = nullptr) {
+    if (inputs.size() != proofs.size() || outputs.size() != proofs.size())
+        throw std::runtime_error("verify_mimc_proofs: one input and one output per proof");
+    std::vector<uint64_t> offsets(proofs.size() + 1, 0);
+    for (size_t i = 0; i < proofs.size(); i++) offsets[i + 1] = offsets[i] + proofs[i].size();
+    std::vector<uint8_t> blob(offsets.back());
+    for (size_t i = 0; i < proofs.size(); i++)
+        if (!proofs[i].empty()) std::memcpy(&blob[offsets[i]], proofs[i].data(), proofs[i].size());
+    std::vector<uint8_t> accept(proofs.size()), st(proofs.size());
+    c.check(stark_mimc_verify_batch_io(c.get(), blob.data(), offsets.data(), proofs.size(),
+                                       inputs.empty() ? nullptr : inputs[0].data(), num_steps,
+                                       round_constants.empty() ? nullptr : round_constants[0].data(), round_constants.size(),
+                                       outputs.empty() ? nullptr : outputs[0].data(), accept.data(), st.data()));
+    if (status) *status = st;
+    return std::vector<bool>(accept.begin(), accept.end());
+}
+
+// Proof generation (the reference's proofs come from an external program, README.md:9): one serialized proof per
+// input, in the format deserializer::from_bytes reads; outputs[i] = mimc(inputs[i], num_steps, round_constants)
+// (src/utils.rs:8-16), the value verify_mimc_proof is called with.
+inline std::vector<std::vector<uint8_t>> mk_mimc_proofs(Context& c, const std::vector<U256>& inputs, size_t num_steps,
+                                                        const std::vector<U256>& round_constants, std::vector<U256>* outputs) {
+    const size_t size = stark_mimc_proof_size(num_steps, round_constants.size());
+    if (size == 0) throw std::runtime_error("mk_mimc_proofs: num_steps / round_constants rejected");
+    std::vector<uint8_t> blob(inputs.size() * size);
+    std::vector<U256> outs(inputs.size());
+    if (!inputs.empty())
+        c.check(stark_mimc_prove_batch(c.get(), inputs[0].data(), inputs.size(), num_steps, round_constants[0].data(),
+                                       round_constants.size(), blob.data(), outs[0].data()));
+    std::vector<std::vector<uint8_t>> proofs(inputs.size());
+    for (size_t i = 0; i < inputs.size(); i++) proofs[i].assign(blob.begin() + i * size, blob.begin() + (i + 1) * size);
+    if (outputs) *outputs = outs;
+    return proofs;
+}
+
 }  // namespace starkhost

@@ -98,6 +98,16 @@ int main(int argc, char** argv) {
         std::vector<bool> acc = verify_mimc_proofs(ctx, inp, 8192, consts, out, {good, bad, good}, &status);
         if (!(acc[0] && !acc[1] && acc[2])) { printf("FAIL: batch accept bits %d %d %d\n", (int)acc[0], (int)acc[1], (int)acc[2]); return 1; }
         if (status[0] != 0 || status[1] == 0) { printf("FAIL: batch status\n"); return 1; }
+        // the prover reproduces the bundled proof from the same instance, and its proofs for other inputs verify
+        std::vector<U256> outs;
+        std::vector<U256> ins = {inp, U256{4, 0, 0, 0, 0, 0, 0, 0}, U256{~0u, ~0u, 0, 0, 0, 0, 0, 1}};
+        std::vector<std::vector<uint8_t>> made = mk_mimc_proofs(ctx, ins, 8192, consts, &outs);
+        if (made[0] != good || outs[0] != out) { printf("FAIL: prover does not reproduce the bundled proof\n"); return 1; }
+        acc = verify_mimc_proofs(ctx, ins, 8192, consts, outs, made, &status);
+        if (!(acc[0] && acc[1] && acc[2])) { printf("FAIL: generated proofs rejected\n"); return 1; }
+        std::swap(outs[1], outs[2]);
+        acc = verify_mimc_proofs(ctx, ins, 8192, consts, outs, made, &status);
+        if (!(acc[0] && !acc[1] && !acc[2])) { printf("FAIL: proofs accepted for the wrong output\n"); return 1; }
     }
     printf("host mirror ok\n");
     return 0;
