@@ -31,7 +31,7 @@ EXPORTS = [
     "stark_fill_random_field_dev", "stark_twiddle_mul_dev", "stark_permute3_dev",
     "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
     "stark_merkle_build", "stark_merkle_build_dev",
-    "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io",
+    "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev",
 ]
 
 
@@ -93,6 +93,8 @@ def load() -> ctypes.CDLL:
     L.stark_mimc_verify_batch.restype = i32
     L.stark_mimc_verify_batch_io.argtypes = [vp, vp, vp, sz, vp, u64, vp, sz, vp, vp, vp]
     L.stark_mimc_verify_batch_io.restype = i32
+    L.stark_mimc_verify_batch_dev.argtypes = [vp, vp, u64, sz, vp, u64, vp, sz, vp, vp, vp]
+    L.stark_mimc_verify_batch_dev.restype = i32
     L.stark_pseudorandom_indices.argtypes = [vp, vp, sz, u32, u32, u32, vp]
     L.stark_pseudorandom_indices.restype = i32
     L.stark_pseudorandom_indices_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]

@@ -58,6 +58,23 @@ def verify_mimc_batch_io(proofs: Sequence[bytes], inputs: Sequence[int], num_ste
     return accept, status
 
 
+def verify_mimc_batch_dev(d_proofs: int, proof_stride: int, n: int, d_inputs: int, num_steps: int,
+                          round_constants: Sequence[int], d_outputs: int,
+                          ctx: _lib.Context | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """verify_mimc_batch_io for proofs, inputs and outputs already in device memory (raw device pointers, e.g. what
+    prover.mk_mimc_proofs_dev / stark_mimc_prove_batch_dev left there): proof i is the proof_stride bytes at
+    d_proofs + i * proof_stride. Returns host arrays (accept, status)."""
+    ctx = ctx or _lib.default_context()
+    rc = np.ascontiguousarray(np.concatenate([_limbs(c % MODULUS) for c in round_constants]) if len(round_constants)
+                              else np.zeros(0, dtype=np.uint32))
+    accept = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.uint8)
+    ctx.check(ctx.lib.stark_mimc_verify_batch_dev(ctx.handle, d_proofs, proof_stride, n, d_inputs, num_steps,
+                                                  rc.ctypes.data if rc.size else None, len(round_constants), d_outputs,
+                                                  accept.ctypes.data if n else None, status.ctypes.data if n else None))
+    return accept, status
+
+
 def verify_mimc_batch_sharded(proofs: Sequence[bytes], inp: int, num_steps: int, round_constants: Sequence[int], output: int,
                               ctx: _lib.Context | None = None, verify=None):
     """The same batch split over the ranks of the default process group (one process per GPU): proofs are

@@ -188,6 +188,7 @@ enum Status : uint8_t {
     ST_BOUNDARY = 7,      // lib.rs:187
     ST_LINEAR_COMB = 8,   // lib.rs:190
     ST_INSTANCE = 9,      // the instance-size asserts at lib.rs:50-51,120-123
+    ST_FAST = 0xFF,       // internal: decided by the fast path (batch_dev.hip), skipped by the general one
 };
 
 struct Params {
@@ -479,34 +480,36 @@ using namespace starkhip::batch;
     catch (...) { return STARK_ERR_HIP; }
 
 
-static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs, const uint32_t* inp,
-                       const uint32_t* output, size_t io_stride, uint64_t num_steps, const uint32_t* round_constants,
-                       size_t n_constants, uint8_t* accept, uint8_t* status) {
-    if (!ctx) return STARK_ERR_INVALID;
-    if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
-    if (((n_proofs || !io_stride) && (!inp || !output)) || (n_constants && !round_constants)) return STARK_ERR_INVALID;
-    for (size_t i = 0; i < n_proofs; i++)
-        if (offsets[i + 1] < offsets[i]) return STARK_ERR_INVALID;
-    auto set_all = [&](uint8_t st) {
-        for (size_t i = 0; i < n_proofs; i++) {
-            accept[i] = st == ST_ACCEPT;
-            if (status) status[i] = st;
-        }
-        return STARK_OK;
-    };
+// Everything verify_mimc_proof derives from (num_steps, round_constants) before it looks at a proof.
+struct Setup {
+    Params P;
+    CheckParams CP;
+    uint32_t* d_mini = nullptr;  // constants_mini_polynomial on the device (when the scalar checks run there)
+    bool field_on_host = false, skip_merkle = false, force_flatten = false;
+    ~Setup() { (void)hipFree(d_mini); }
+};
+
+// early: ST_ACCEPT when proofs have to be looked at, else the status every proof gets (lib.rs:101-111, :120-123)
+static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_constants, size_t n_constants, Setup& S,
+                      uint8_t& early) {
+    Params& P = S.P;
+    CheckParams& CP = S.CP;
+    early = ST_ACCEPT;
     // parameter checks of lib.rs:101-111: the reference returns false
     auto pow2 = [](uint64_t x) { return x && !(x & (x - 1)); };
-    if (num_steps > (1ull << 32) / 8 || !pow2(num_steps) || !pow2(n_constants) || n_constants > num_steps) return set_all(ST_PARAMS);
-    Params P;
-    P.inputs = inp;
-    P.outputs = output;
-    P.io_stride = io_stride;
+    if (num_steps > (1ull << 32) / 8 || !pow2(num_steps) || !pow2(n_constants) || n_constants > num_steps) {
+        early = ST_PARAMS;
+        return STARK_OK;
+    }
     P.num_steps = num_steps;
     P.precision = num_steps * 8;
     P.skips = 8;
     P.skips2 = num_steps / n_constants;
     // asserts at lib.rs:120 (num_steps), :123 (val, which fixes 64 round constants), :50 (rou_deg == 65536)
-    if (num_steps != 8192 || n_constants != 64) return set_all(ST_INSTANCE);
+    if (num_steps != 8192 || n_constants != 64) {
+        early = ST_INSTANCE;
+        return STARK_OK;
+    }
     {
         // G2 = 7^((p-1)/precision) (lib.rs:114); (p-1)/2^16 = p >> 16 because p-1 is a multiple of 2^32
         U256 e = hostfe::MODULUS;
@@ -532,33 +535,58 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     }
     // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host
     const char* fenv = getenv("STARKHIP_BATCH_FIELD");
-    const bool field_on_host = fenv && strcmp(fenv, "host") == 0;
+    S.field_on_host = fenv && strcmp(fenv, "host") == 0;
     // diagnostic: let the scalar checks decide even when a branch mismatched (compares the host and device
     // versions of those checks on corrupted values); never set in production
-    const bool skip_merkle = getenv("STARKHIP_BATCH_IGNORE_MERKLE") != nullptr;
+    S.skip_merkle = getenv("STARKHIP_BATCH_IGNORE_MERKLE") != nullptr;
     const char* menv = getenv("STARKHIP_BATCH_MERKLE");
-    const bool force_flatten = menv && strcmp(menv, "flatten") == 0;
-    CheckParams CP;
-    uint32_t* d_mini = nullptr;
-    {
-        hostfe::to_limbs(P.g2, CP.g2);
-        hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
-        hostfe::to_limbs(P.last_step, CP.last_step);
-        CP.precision = (uint32_t)P.precision;
-        CP.log_steps = CP.log_skips2 = 0;
-        while ((1ull << CP.log_steps) < P.num_steps) CP.log_steps++;
-        while ((1ull << CP.log_skips2) < P.skips2) CP.log_skips2++;
-        CP.n_coeffs = (uint32_t)P.mini_poly.size();
-        if (!field_on_host) {
-            std::vector<uint32_t> mp(8 * P.mini_poly.size());
-            for (size_t i = 0; i < P.mini_poly.size(); i++) hostfe::to_limbs(hostfe::canon(P.mini_poly[i]), &mp[8 * i]);
-            if (hipMalloc((void**)&d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
-            if (hipMemcpy(d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-                (void)hipFree(d_mini);
-                return STARK_ERR_HIP;
-            }
-        }
+    S.force_flatten = menv && strcmp(menv, "flatten") == 0;
+    hostfe::to_limbs(P.g2, CP.g2);
+    hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
+    hostfe::to_limbs(P.last_step, CP.last_step);
+    CP.precision = (uint32_t)P.precision;
+    CP.log_steps = CP.log_skips2 = 0;
+    while ((1ull << CP.log_steps) < P.num_steps) CP.log_steps++;
+    while ((1ull << CP.log_skips2) < P.skips2) CP.log_skips2++;
+    CP.n_coeffs = (uint32_t)P.mini_poly.size();
+    if (!S.field_on_host) {
+        std::vector<uint32_t> mp(8 * P.mini_poly.size());
+        for (size_t i = 0; i < P.mini_poly.size(); i++) hostfe::to_limbs(hostfe::canon(P.mini_poly[i]), &mp[8 * i]);
+        if (hipMalloc((void**)&S.d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
+        if (hipMemcpy(S.d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return STARK_ERR_HIP;
     }
+    return STARK_OK;
+}
+
+static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs, const uint32_t* inp,
+                       const uint32_t* output, size_t io_stride, uint64_t num_steps, const uint32_t* round_constants,
+                       size_t n_constants, uint8_t* accept, uint8_t* status) {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
+    if (((n_proofs || !io_stride) && (!inp || !output)) || (n_constants && !round_constants)) return STARK_ERR_INVALID;
+    for (size_t i = 0; i < n_proofs; i++)
+        if (offsets[i + 1] < offsets[i]) return STARK_ERR_INVALID;
+    auto set_all = [&](uint8_t st) {
+        for (size_t i = 0; i < n_proofs; i++) {
+            accept[i] = st == ST_ACCEPT;
+            if (status) status[i] = st;
+        }
+        return STARK_OK;
+    };
+    Setup S;
+    uint8_t early;
+    {
+        int rc = make_setup(ctx, num_steps, round_constants, n_constants, S, early);
+        if (rc != STARK_OK) return rc;
+    }
+    if (early != ST_ACCEPT) return set_all(early);
+    Params& P = S.P;
+    P.inputs = inp;
+    P.outputs = output;
+    P.io_stride = io_stride;
+    const CheckParams& CP = S.CP;
+    const uint32_t* d_mini = S.d_mini;
+    const bool field_on_host = S.field_on_host, skip_merkle = S.skip_merkle, force_flatten = S.force_flatten;
     unsigned threads = std::thread::hardware_concurrency();
     if (const char* s = getenv("STARKHIP_HOST_THREADS")) threads = (unsigned)atoi(s);
     threads = std::max(1u, std::min(threads, 16u));
@@ -567,7 +595,10 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
 
     // STARKHIP_BATCH_TIMING=1 prints per-stage wall time to stderr
     const bool timing = getenv("STARKHIP_BATCH_TIMING") != nullptr;
-    double t_parse = 0, t_bucket = 0, t_flatten = 0, t_merkle = 0, t_field = 0;
+    double t_parse = 0, t_bucket = 0, t_flatten = 0, t_merkle = 0, t_field = 0, t_classify = 0, t_fast = 0;
+    // STARKHIP_BATCH_PATH=general: every proof takes the parsing path (the diagnostic switches above imply it)
+    const char* penv = getenv("STARKHIP_BATCH_PATH");
+    const bool use_fast = !(penv && strcmp(penv, "general") == 0) && !field_on_host && !force_flatten && !skip_merkle;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t c0 = 0; c0 < n_proofs;) {
         size_t c1 = c0 + 1;
@@ -575,8 +606,23 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         const size_t m = c1 - c0;
         std::vector<ProofWork> work(m);
         double t0 = now();
+        // proofs with the fixed instance's structure words are decided on the device without being parsed here
+        std::vector<uint8_t> canon(m, 0);
+        if (use_fast)
+            parallel_for((m + 63) / 64, threads, [&](size_t blk) {
+                for (size_t i = blk * 64; i < std::min(m, blk * 64 + 64); i++) {
+                    const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
+                    canon[i] = (a - offsets[c0]) % 4 == 0 && fast_is_canonical(proofs + a, (size_t)(b - a));
+                }
+            });
+        t_classify += now() - t0;
+        t0 = now();
         parallel_for(m, threads, [&](size_t i) {
             ProofWork& pw = work[i];
+            if (canon[i]) {
+                pw.status = ST_FAST;
+                return;
+            }
             const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
             if (!parse_proof(proofs + a, (size_t)(b - a), pw.proof)) {
                 pw.status = ST_PARSE;
@@ -659,7 +705,6 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                          o_acc = o_idx + up(4 * total), bytes = o_acc + up(total);
             uint8_t* d = nullptr;
             if (hipMalloc((void**)&d, bytes) != hipSuccess) {
-                (void)hipFree(d_mini);
                 return STARK_ERR_NOMEM;
             }
             hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
@@ -680,7 +725,6 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             (void)hipFree(d);
             if (e != hipSuccess) {
-                (void)hipFree(d_mini);
                 return STARK_ERR_HIP;
             }
             for (size_t k = 0; k < total; k++)
@@ -707,7 +751,6 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                                                roots.data(), (uint32_t)(roots.size() / 32), bk.root_id.data(), n, acc.data(),
                                                nullptr);
             if (rc != STARK_OK) {
-                (void)hipFree(d_mini);
                 return rc;
             }
             for (size_t k = 0; k < n; k++)
@@ -725,21 +768,46 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         } else {
             int rc = device_field_checks(ctx, work, c0, P, CP, d_mini, threads);
             if (rc != STARK_OK) {
-                (void)hipFree(d_mini);
                 return rc;
             }
         }
         t_field += now() - t0;
+        t0 = now();
+        {
+            std::vector<uint64_t> bases;
+            std::vector<size_t> who;
+            for (size_t i = 0; i < m; i++)
+                if (canon[i]) {
+                    bases.push_back(offsets[c0 + i] - offsets[c0]);
+                    who.push_back(i);
+                }
+            if (!who.empty()) {
+                std::vector<uint32_t> io(16 * who.size());
+                parallel_for((who.size() + 255) / 256, threads, [&](size_t blk) {
+                    for (size_t k = blk * 256; k < std::min(who.size(), blk * 256 + 256); k++) {
+                        const U256 in = P.inp(c0 + who[k]);
+                        hostfe::to_limbs(in, &io[16 * k]);
+                        hostfe::to_limbs(fe_mul(fe_sub(P.output(c0 + who[k]), in), P.inv_last_m1), &io[16 * k + 8]);
+                    }
+                });
+                std::vector<uint8_t> st(who.size());
+                int rc = fast_verify(ctx, chunk_base, chunk_len, bases.data(), io.data(), who.size(), CP, d_mini, st.data());
+                if (rc != STARK_OK) {
+                    return rc;
+                }
+                for (size_t k = 0; k < who.size(); k++) work[who[k]].status = st[k];
+            }
+        }
+        t_fast += now() - t0;
         for (size_t i = 0; i < m; i++) {
             accept[c0 + i] = work[i].status == ST_ACCEPT;
             if (status) status[c0 + i] = work[i].status;
         }
         c0 = c1;
     }
-    (void)hipFree(d_mini);
     if (timing)
-        fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
-                n_proofs, t_parse, t_bucket, t_flatten, t_merkle, t_field);
+        fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: structure check %.3f s, fast path (upload + kernels) %.3f s; general path: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
+                n_proofs, t_classify, t_fast, t_parse, t_bucket, t_flatten, t_merkle, t_field);
     return STARK_OK;
 }
 
@@ -747,6 +815,96 @@ extern "C" int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, co
                                        const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
                                        size_t n_constants, const uint32_t output[8], uint8_t* accept, uint8_t* status) try {
     return verify_impl(ctx, proofs, offsets, n_proofs, inp, output, 0, num_steps, round_constants, n_constants, accept, status);
+} STARK_CATCH
+
+// Proofs already in device memory (what stark_mimc_prove_batch_dev leaves there): the structure check, the index
+// sampling, the branches and the scalar checks all run where the bytes are; only proofs of another structure
+// (which the reference can only reject or panic on, or whose `points` component has another length) are copied
+// to the host and take the general path.
+extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs, uint64_t proof_stride, size_t n_proofs,
+                                           const void* d_inputs, uint64_t num_steps, const uint32_t* round_constants,
+                                           size_t n_constants, const void* d_outputs, uint8_t* accept, uint8_t* status) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (n_proofs && (!d_proofs || !d_inputs || !d_outputs || !accept)) return STARK_ERR_INVALID;
+    if (n_constants && !round_constants) return STARK_ERR_INVALID;
+    if (n_proofs == 0) return STARK_OK;
+    Setup S;
+    uint8_t early;
+    int rc = make_setup(ctx, num_steps, round_constants, n_constants, S, early);
+    if (rc != STARK_OK) return rc;
+    if (early != ST_ACCEPT) {
+        for (size_t i = 0; i < n_proofs; i++) {
+            accept[i] = 0;
+            if (status) status[i] = early;
+        }
+        return STARK_OK;
+    }
+    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+    const char* penv = getenv("STARKHIP_BATCH_PATH");
+    const bool use_fast = !(penv && strcmp(penv, "general") == 0) && !S.field_on_host && !S.force_flatten && !S.skip_merkle;
+    std::vector<uint8_t> canon(n_proofs, 0), stv(n_proofs, 0);
+    if (use_fast && (rc = fast_classify_resident(ctx, (const uint8_t*)d_proofs, proof_stride, n_proofs, canon.data())) != STARK_OK)
+        return rc;
+    std::vector<uint64_t> bases;
+    std::vector<uint32_t> who;
+    std::vector<size_t> rest;
+    for (size_t i = 0; i < n_proofs; i++) {
+        if (canon[i]) {
+            bases.push_back(proof_stride * i);
+            who.push_back((uint32_t)i);
+        } else {
+            rest.push_back(i);
+        }
+    }
+    // descriptors and lanes take about 83 KB per proof: chunks of at most 2^16 proofs
+    for (size_t k0 = 0; k0 < who.size(); k0 += 65535) {
+        const size_t mc = std::min<size_t>(65535, who.size() - k0);
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_who = up(8 * mc), o_io = o_who + up(4 * mc);
+        uint8_t* d = nullptr;
+        if (hipMalloc((void**)&d, o_io + up(64 * mc)) != hipSuccess) return STARK_ERR_NOMEM;
+        struct Free {
+            uint8_t* p;
+            ~Free() { (void)hipFree(p); }
+        } guard{d};
+        uint32_t inv[8];
+        hostfe::to_limbs(S.P.inv_last_m1, inv);
+        if (hipMemcpyAsync(d, bases.data() + k0, 8 * mc, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_who, who.data() + k0, 4 * mc, hipMemcpyHostToDevice, st) != hipSuccess)
+            return STARK_ERR_HIP;
+        rc = fast_make_io(ctx, (const uint32_t*)d_inputs, (const uint32_t*)d_outputs, (const uint32_t*)(d + o_who), mc, inv,
+                          (uint32_t*)(d + o_io));
+        std::vector<uint8_t> out(mc);
+        if (rc == STARK_OK)
+            rc = fast_verify_resident(ctx, (const uint8_t*)d_proofs, (const uint64_t*)d, (const uint32_t*)(d + o_io), mc, S.CP,
+                                      S.d_mini, out.data());
+        if (rc != STARK_OK) return rc;
+        for (size_t k = 0; k < mc; k++) stv[who[k0 + k]] = out[k];
+    }
+    if (!rest.empty()) {
+        std::vector<uint8_t> blob(rest.size() * proof_stride), a2(rest.size()), s2(rest.size());
+        std::vector<uint32_t> in(8 * rest.size()), out(8 * rest.size());
+        std::vector<uint64_t> offs(rest.size() + 1);
+        for (size_t k = 0; k < rest.size(); k++) {
+            offs[k] = proof_stride * k;
+            if (hipMemcpyAsync(&blob[proof_stride * k], (const uint8_t*)d_proofs + proof_stride * rest[k], proof_stride,
+                               hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&in[8 * k], (const uint32_t*)d_inputs + 8 * rest[k], 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&out[8 * k], (const uint32_t*)d_outputs + 8 * rest[k], 32, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return STARK_ERR_HIP;
+        }
+        offs[rest.size()] = proof_stride * rest.size();
+        if (hipStreamSynchronize(st) != hipSuccess) return STARK_ERR_HIP;
+        rc = verify_impl(ctx, blob.data(), offs.data(), rest.size(), in.data(), out.data(), 8, num_steps, round_constants,
+                         n_constants, a2.data(), s2.data());
+        if (rc != STARK_OK) return rc;
+        for (size_t k = 0; k < rest.size(); k++) stv[rest[k]] = s2[k];
+    }
+    for (size_t i = 0; i < n_proofs; i++) {
+        accept[i] = stv[i] == ST_ACCEPT;
+        if (status) status[i] = stv[i];
+    }
+    return STARK_OK;
 } STARK_CATCH
 
 extern "C" int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,

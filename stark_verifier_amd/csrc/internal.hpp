@@ -113,6 +113,24 @@ constexpr size_t CHECK_PROOF_BYTES = 192;
 hipError_t launch_constraint_check(const ConstraintLane* lanes, size_t n, const CheckParams& P, const uint8_t* kk,
                                    const uint32_t* mini_poly, uint8_t* status, hipStream_t stream);
 
+// ---- batch driver, fast path for proofs with the fixed instance's structure (batch_dev.hip) ----
+namespace batch {
+size_t fast_proof_size();
+bool fast_is_canonical(const uint8_t* proof, size_t len);
+// chunk: proof bytes (host); bases[i]: offset of canonical proof i inside it (a multiple of 4); io: per proof 8 + 8
+// canonical limbs (input, slope of the boundary interpolant); status_out[i]: 0 accepted, else the code of a failing check
+int fast_verify(stark_ctx* ctx, const uint8_t* chunk, size_t chunk_len, const uint64_t* bases, const uint32_t* io, size_t mc,
+                const CheckParams& CP, const uint32_t* d_mini, uint8_t* status_out);
+// the same with the proofs, offsets and (input, slope) pairs already in device memory
+int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io, size_t mc,
+                         const CheckParams& CP, const uint32_t* d_mini, uint8_t* status_out);
+// structure check of device-resident proofs at d_proofs + i * stride; canonical_out is a host array
+int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t n, uint8_t* canonical_out);
+// d_io[k] = (canonical input, slope) of proof d_who[k] from device-resident n x 8-limb inputs / outputs
+int fast_make_io(stark_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_outputs, const uint32_t* d_who, size_t mc,
+                 const uint32_t inv_last_m1[8], uint32_t* d_io);
+}  // namespace batch
+
 // sharded-transform helpers (shard.hip)
 hipError_t launch_twiddle_mul(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0,
                               uint32_t log_order, uint32_t lo_bits, const uint32_t* lo, const uint32_t* hi,

@@ -36,3 +36,13 @@ def mk_mimc_proofs(inputs: Sequence[int], num_steps: int, round_constants: Seque
     blob = proofs.tobytes()
     outs = [int.from_bytes(outputs[8 * i:8 * i + 8].astype("<u4").tobytes(), "little") for i in range(n)]
     return [blob[i * size:(i + 1) * size] for i in range(n)], outs
+
+
+def mk_mimc_proofs_dev(d_inputs: int, n: int, num_steps: int, round_constants: Sequence[int], d_proofs: int, proof_stride: int,
+                       d_outputs: int, ctx: _lib.Context | None = None, stream: int | None = None) -> None:
+    """Device-resident version: d_inputs / d_outputs are n x 8 limbs, proof i is written at d_proofs + i * proof_stride
+    (raw device pointers, 16-byte aligned). Queued on `stream` (default: the context's); does not synchronise."""
+    ctx = ctx or _lib.default_context()
+    rc = np.ascontiguousarray(np.concatenate([_limbs(int(c) % MODULUS) for c in round_constants]))
+    ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inputs, n, num_steps, rc.ctypes.data, len(round_constants),
+                                                 d_proofs, proof_stride, d_outputs, stream))

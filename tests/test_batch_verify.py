@@ -237,3 +237,40 @@ def test_fuzzed_proof_bytes_never_crash_and_match_the_restatement(proof_bytes):
     expect = [_ref_accepts(b, 3, 8192, consts, output) for b in blobs]
     assert [bool(a) for a in accept] == expect
     assert all((s == 0) == bool(a) for a, s in zip(accept, status))
+
+
+def test_fast_and_general_paths_agree(proof_bytes, monkeypatch):
+    """Proofs whose structure words are the fixed instance's are decided on the device without host parsing;
+    STARKHIP_BATCH_PATH=general sends every proof through the parsing path. Both must give the same accept bit
+    and the same status for every proof: damaged values, witnesses and roots (fast path), damaged lengths and
+    truncations (general path either way), and valid proofs of other inputs."""
+    from stark_verifier_amd import batch, prover
+    consts = rv.mimc_constants()
+    rng = np.random.default_rng(21)
+    inputs = [3, 5, int.from_bytes(rng.bytes(32), "little") % rv.P]
+    made, outs = prover.mk_mimc_proofs(inputs, 8192, consts)
+    assert made[0] == proof_bytes
+    v = _variants(proof_bytes)
+    blobs, ins, outs_ = [], [], []
+    for k in v:
+        blobs.append(v[k]); ins.append(3); outs_.append(outs[0])
+    n = len(proof_bytes)
+    for t in range(200):
+        src = t % 3
+        b = bytearray(made[src])
+        if t % 4 == 3:
+            o = 4 * int(rng.integers(16, n // 4 - 1))            # a whole word: often a structure word
+            b[o:o + 4] = struct.pack("<I", int(rng.choice([0, 32, 96, 480, 2**31])))
+        else:
+            b[int(rng.integers(0, n))] ^= 1 << int(rng.integers(8))
+        blobs.append(bytes(b)); ins.append(inputs[src]); outs_.append(outs[src])
+    for src in range(3):
+        blobs.append(made[src]); ins.append(inputs[src]); outs_.append(outs[src])
+        blobs.append(made[src]); ins.append(inputs[src]); outs_.append(outs[(src + 1) % 3])   # wrong output
+    a_fast, s_fast = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs_)
+    monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
+    a_gen, s_gen = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs_)
+    assert np.array_equal(a_fast, a_gen)
+    assert np.array_equal(s_fast, s_gen), [(i, int(x), int(y)) for i, (x, y) in enumerate(zip(s_fast, s_gen)) if x != y]
+    assert list(a_fast[-6:]) == [1, 0, 1, 0, 1, 0] and list(s_fast[-6:]) == [0, 7, 0, 7, 0, 7]
+    assert set(s_fast.tolist()) >= {0, 2, 4, 7}

@@ -103,3 +103,51 @@ def test_device_prover_rejects_bad_parameters():
     with pytest.raises(_lib.InvalidArgument):
         prover.mk_mimc_proofs([1], 100, [1, 2])
     assert prover.mk_mimc_proofs([], 64, [1, 2]) == ([], [])
+
+
+@pytest.mark.gpu
+def test_prove_and_verify_without_leaving_the_device(monkeypatch):
+    """stark_mimc_prove_batch_dev -> stark_mimc_verify_batch_dev on the same device buffers; then damage some proofs
+    in place (values, witnesses, structure words, an input) and compare with the host-buffer verifier on a copy."""
+    import torch
+    from stark_verifier_amd import _lib, batch, prover
+    from stark_verifier_amd.fft import _limbs
+    consts = rv.mimc_constants()
+    n = 24
+    rng = np.random.default_rng(5)
+    inputs = [3] + [int.from_bytes(rng.bytes(32), "little") % P for _ in range(n - 1)]
+    size = prover.mimc_proof_size(8192, 64)
+    stride = size + 12          # a few ignored bytes after each proof
+    ctx = _lib.default_context()
+    d_in = torch.from_numpy(np.concatenate([_limbs(x) for x in inputs]).view(np.int32)).cuda()
+    d_out = torch.zeros(8 * n, dtype=torch.int32, device="cuda")
+    d_proofs = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    prover.mk_mimc_proofs_dev(d_in.data_ptr(), n, 8192, consts, d_proofs.data_ptr(), stride, d_out.data_ptr())
+    ctx.synchronize()
+    assert bytes(d_proofs[:size].cpu().numpy().tobytes()) == open(GOLD, "rb").read()
+    a, s = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in.data_ptr(), 8192, consts, d_out.data_ptr())
+    assert a.tolist() == [1] * n and s.tolist() == [0] * n
+    # damage in place
+    view = d_proofs.view(n, stride)
+    view[1, 5000] ^= 1          # some value or witness
+    view[2, 70] ^= 4            # root2 of the first layer
+    view[3, 100] = 77           # the first branch count: structure word -> general path
+    view[4, size - 40] ^= 8     # last witness of the last branch
+    view[5, 64] = 3             # element tag: parser error
+    d_in2 = d_in.clone()
+    d_in2[8 * 6] += 1           # proof 6 checked against another input
+    torch.cuda.synchronize()
+    a, s = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in2.data_ptr(), 8192, consts, d_out.data_ptr())
+    host = d_proofs.cpu().numpy()
+    blobs = [host[i * stride:(i + 1) * stride].tobytes() for i in range(n)]
+    ins = list(inputs)
+    ins[6] += 1
+    outs = [int.from_bytes(d_out[8 * i:8 * i + 8].cpu().numpy().astype("<u4").tobytes(), "little") for i in range(n)]
+    a_h, s_h = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs)
+    assert np.array_equal(a, a_h) and np.array_equal(s, s_h)
+    assert a.tolist() == [1, 0, 0, 0, 0, 0, 0] + [1] * (n - 7)
+    assert s[1] == 4 and s[2] == 4 and s[4] == 4 and s[5] == 2 and s[6] == 7 and s[3] != 0
+    monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
+    a_g, s_g = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in2.data_ptr(), 8192, consts, d_out.data_ptr())
+    assert np.array_equal(a, a_g) and np.array_equal(s, s_g)

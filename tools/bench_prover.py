@@ -61,4 +61,11 @@ if do_verify:
     dt_v = time.perf_counter() - t0
     res.update({"verify_seconds": dt_v, "verify_proofs_per_s": N / dt_v, "all_accepted": bool(acc.all()),
                 "distinct_proofs": len({proofs[i * size:i * size + 64].tobytes() for i in range(N)})})
+    acc = np.zeros(N, dtype=np.uint8); st = np.zeros(N, dtype=np.uint8)
+    run_dev(N)
+    t0 = time.perf_counter()
+    ctx.check(lib.stark_mimc_verify_batch_dev(ctx.handle, d_proofs.data_ptr(), size, N, d_in.data_ptr(), steps, rcs.ctypes.data,
+                                              len(consts), d_out.data_ptr(), acc.ctypes.data, st.ctypes.data))
+    dt_vd = time.perf_counter() - t0
+    res.update({"verify_resident_seconds": dt_vd, "verify_resident_proofs_per_s": N / dt_vd, "resident_all_accepted": bool(acc.all())})
 print(json.dumps(res))
