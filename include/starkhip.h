@@ -192,10 +192,13 @@ int stark_pseudorandom_indices_dev(stark_ctx* ctx, const void* d_seeds, size_t n
  *   4 a recomputed Merkle root differs 5 low-degree check (:85)   6 transition (:181)
  *   7 boundary (:187)                  8 linear combination (:190)
  *   9 instance-size asserts (:50-51, :120-123: num_steps 8192, 64 round constants)
- * All Merkle branches of a chunk of proofs (1,240 per proof) are hashed by the device in one call per
- * (value size, witness count); parsing, index sampling (src/utils.rs:53-94) and the scalar field checks
- * run on host threads (STARKHIP_HOST_THREADS, default min(cores, 16)). As in the reference, the final
- * FRI "points" component is read and not verified (src/deserializer.rs:47-59, src/lib.rs:94).
+ * A proof whose structure words (branch counts, value sizes, witness counts, element tags) are those of an
+ * 8192-step proof - every proof the reference accepts is one - is not parsed on the host: its bytes are
+ * uploaded and the device samples the indices (src/utils.rs:53-94), hashes the 1,240 branches where they lie
+ * and runs the scalar field checks. Any other proof is parsed by host threads (STARKHIP_HOST_THREADS, default
+ * min(cores, 16)), its branches are hashed by the device in one call per (value size, witness count), and
+ * the same check kernels decide. As in the reference, the final FRI "points" component is read and not
+ * verified (src/deserializer.rs:47-59, src/lib.rs:94).
  */
 int stark_mimc_verify_batch(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
                             const uint32_t inp[8], uint64_t num_steps, const uint32_t* round_constants,
