@@ -709,7 +709,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
             }
             hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
             std::vector<uint8_t> acc(total);
-            hipError_t e = hipMemcpyAsync(d, chunk_base, chunk_len, hipMemcpyHostToDevice, st);
+            hipError_t e = copy_h2d(ctx, d, chunk_base, chunk_len, st);
             if (e == hipSuccess) e = hipMemcpyAsync(d + o_rec, rec_off.data(), 8 * total, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(d + o_root, root_off.data(), 8 * total, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(d + o_idx, idx.data(), 4 * total, hipMemcpyHostToDevice, st);

@@ -473,7 +473,7 @@ int fast_verify(stark_ctx* ctx, const uint8_t* chunk, size_t chunk_len, const ui
         uint8_t* p;
         ~Free() { (void)hipFree(p); }
     } guard{d};
-    F_TRY(hipMemcpyAsync(d, chunk, chunk_len, hipMemcpyHostToDevice, st));
+    F_TRY(copy_h2d(ctx, d, chunk, chunk_len, st));
     F_TRY(hipMemcpyAsync(d + o_base, bases, 8 * mc, hipMemcpyHostToDevice, st));
     F_TRY(hipMemcpyAsync(d + o_io, io, 64 * mc, hipMemcpyHostToDevice, st));
     return fast_verify_resident(ctx, d, (const uint64_t*)(d + o_base), (const uint32_t*)(d + o_io), mc, CP, d_mini, status_out);

@@ -8,6 +8,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/starkhip.h"
@@ -56,9 +57,100 @@ struct stark_ctx {
     size_t table_budget = (size_t)8 << 30;   // twiddle tables kept across calls (STARKHIP_TABLE_MB)
     uint64_t use_counter = 0;
     std::unique_ptr<CtxAttachment> attach[CTX_SLOTS];
+    // pinned staging for copies from / to pageable host memory
+    char* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_tried = false;
+    unsigned copy_threads = 8;
 };
 
 namespace starkhip {
+
+namespace {
+constexpr size_t PIN_BYTES = (size_t)64 << 20;   // each of the two staging buffers
+constexpr size_t STAGE_MIN = (size_t)8 << 20;    // smaller copies go straight through hipMemcpyAsync
+
+bool pin_ready(stark_ctx* ctx) {
+    if (!ctx->pin_tried) {
+        ctx->pin_tried = true;
+        const char* off = getenv("STARKHIP_PINNED");
+        if (off && atoi(off) == 0 && *off) return false;
+        bool ok = hipHostMalloc((void**)&ctx->pin[0], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void**)&ctx->pin[1], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
+                  hipEventCreateWithFlags(&ctx->pin_ev[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ctx->pin_ev[1], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; i++) {
+                if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+                if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+                ctx->pin[i] = nullptr;
+                ctx->pin_ev[i] = nullptr;
+            }
+        }
+        if (const char* t = getenv("STARKHIP_HOST_THREADS"))
+            if (atoi(t) > 0) ctx->copy_threads = (unsigned)atoi(t);
+        if (ctx->copy_threads > 16) ctx->copy_threads = 16;
+    }
+    return ctx->pin[0] != nullptr;
+}
+
+void par_copy(char* dst, const char* src, size_t n, unsigned threads) {
+    if (threads <= 1 || n < ((size_t)1 << 20)) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = ((n + threads - 1) / threads + 4095) & ~(size_t)4095;
+    for (unsigned i = 0; i < threads; i++) {
+        const size_t lo = per * i, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto& t : pool) t.join();
+}
+}  // namespace
+
+hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t stream) {
+    if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
+    hipError_t e = hipSuccess;
+    size_t k = 0;
+    for (size_t o = 0; o < n && e == hipSuccess; o += PIN_BYTES, k++) {
+        const size_t len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
+        char* buf = ctx->pin[k & 1];
+        if (k >= 2) e = hipEventSynchronize(ctx->pin_ev[k & 1]);  // the transfer that last used this buffer
+        if (e != hipSuccess) break;
+        par_copy(buf, (const char*)src + o, len, ctx->copy_threads);
+        e = hipMemcpyAsync((char*)d_dst + o, buf, len, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[k & 1], stream);
+    }
+    // the buffers are reused by the next call: wait for the transfers that still read them
+    for (int i = 0; i < 2 && e == hipSuccess; i++)
+        if (k > (size_t)i) e = hipEventSynchronize(ctx->pin_ev[i]);
+    return e;
+}
+
+hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipStream_t stream) {
+    if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) {
+        hipError_t e = hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream);
+        return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+    }
+    hipError_t e = hipSuccess;
+    const size_t chunks = (n + PIN_BYTES - 1) / PIN_BYTES;
+    for (size_t k = 0; k <= chunks && e == hipSuccess; k++) {
+        if (k < chunks) {
+            const size_t o = k * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
+            e = hipMemcpyAsync(ctx->pin[k & 1], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[k & 1], stream);
+        }
+        if (k >= 1 && e == hipSuccess) {
+            const size_t o = (k - 1) * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
+            e = hipEventSynchronize(ctx->pin_ev[(k - 1) & 1]);
+            if (e == hipSuccess) par_copy((char*)dst + o, ctx->pin[(k - 1) & 1], len, ctx->copy_threads);
+        }
+    }
+    return e;
+}
+
 CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot) {
     return ctx && slot >= 0 && slot < CTX_SLOTS ? ctx->attach[slot].get() : nullptr;
 }
@@ -550,6 +642,10 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     for (auto& p : ctx->shard_tables) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -631,10 +727,10 @@ int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batc
     size_t bytes = (batch << log_n) * 32;
     int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, bytes);
     if (rc != STARK_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->io, limbs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, copy_h2d(ctx, ctx->io, limbs, bytes, ctx->stream));
     rc = ntt_common(ctx, ctx->io, ctx->io, log_n, batch, root_of_unity, inverse, ctx->stream);
     if (rc != STARK_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(limbs, ctx->io, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, copy_d2h(ctx, limbs, ctx->io, bytes, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 } STARK_CATCH
@@ -709,9 +805,9 @@ int stark_merkle_verify_batch(stark_ctx* ctx, const uint8_t* values, const uint8
     uint8_t *d_val = base, *d_sib = d_val + sz_val, *d_wit = d_sib + sz_val, *d_idx = d_wit + sz_wit;
     uint8_t *d_rid = d_idx + sz_idx, *d_roots = d_rid + sz_idx, *d_acc = d_roots + sz_roots, *d_dig = d_acc + sz_acc;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(d_val, values, n * value_size, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_sib, siblings, n * value_size, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_wit, witnesses, (size_t)num_witnesses * n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, copy_h2d(ctx, d_val, values, n * value_size, s));
+    HIP_TRY(ctx, copy_h2d(ctx, d_sib, siblings, n * value_size, s));
+    HIP_TRY(ctx, copy_h2d(ctx, d_wit, witnesses, (size_t)num_witnesses * n * 32, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, n * 4, hipMemcpyHostToDevice, s));
     if (root_ids) HIP_TRY(ctx, hipMemcpyAsync(d_rid, root_ids, n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_roots, roots, (size_t)num_roots * 32, hipMemcpyHostToDevice, s));
@@ -743,9 +839,9 @@ int stark_merkle_build(stark_ctx* ctx, const uint8_t* leaves, unsigned log_leave
     if (rc != STARK_OK) return rc;
     uint8_t* d = (uint8_t*)ctx->io;
     HIP_TRY(ctx, hipMemsetAsync(d, 0, 32, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d + 32 * L, leaves, 32 * L, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, copy_h2d(ctx, d + 32 * L, leaves, 32 * L, ctx->stream));
     HIP_TRY(ctx, launch_merkle_build(d, log_leaves, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(nodes, d, 64 * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, copy_d2h(ctx, nodes, d, 64 * L, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 } STARK_CATCH

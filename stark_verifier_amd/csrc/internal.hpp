@@ -19,6 +19,13 @@ CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot);
 void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a);
 void ctx_set_error(stark_ctx* ctx, const char* text);
 
+// Copies between ordinary (pageable) host memory and the device through two pinned staging buffers of the context:
+// host threads fill or drain one while the DMA engine moves the other (about twice the rate of a direct copy from
+// pageable memory). copy_h2d returns once `src` has been read completely (the transfers are queued on `stream`);
+// copy_d2h returns once `dst` is complete. Small copies and contexts without pinned memory use hipMemcpyAsync.
+hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t stream);
+hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipStream_t stream);
+
 // ---- merkle.hip ----
 hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, uint32_t value_size,
                                 const uint8_t* witnesses, uint32_t num_witnesses, const uint32_t* indices,

@@ -834,7 +834,7 @@ extern "C" int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, si
         if (!p.valid) return STARK_OK;
         p.valid = false;
         P_TRY(hipStreamWaitEvent(R.cs, R.ev[p.buf], 0));
-        P_TRY(hipMemcpyAsync(proofs + psz * p.first, bufs[p.buf], p.m * psz, hipMemcpyDeviceToHost, R.cs));
+        P_TRY(copy_d2h(ctx, proofs + psz * p.first, bufs[p.buf], p.m * psz, R.cs));
         P_TRY(hipStreamSynchronize(R.cs));
         return STARK_OK;
     };
