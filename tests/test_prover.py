@@ -36,6 +36,14 @@ def test_oracle_prover_small_instance_shapes():
     assert len(pr.merkle_branches.branches) == 160 and len(pr.linear_comb_branches.branches) == 80
 
 
+def test_proof_size_of_the_fixed_instance_matches_the_fixture():
+    """Pure host arithmetic over the wire format: no device needed."""
+    from stark_verifier_amd import prover
+    assert prover.mimc_proof_size(8192, 64) == os.path.getsize(GOLD)
+    assert prover.mimc_proof_size(64, 16) == len(oprover.mk_mimc_proof(5, 64, [(i ** 7) ^ 42 for i in range(16)])[0])
+    assert prover.mimc_proof_size(8, 4) == 0 and prover.mimc_proof_size(8192, 3) == 0
+
+
 @pytest.mark.gpu
 def test_device_prover_reproduces_the_reference_fixture():
     from stark_verifier_amd import prover
