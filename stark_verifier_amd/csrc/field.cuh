@@ -43,7 +43,9 @@ __device__ __forceinline__ uint32_t subb(uint32_t a, uint32_t b, uint32_t& borro
 // Lane-wise select through a 0 / 0xFFFFFFFF mask: one v_bitop3_b32. (v_cndmask_b32 reading VCC
 // issues several times slower than this on gfx950 when used back to back.)
 __device__ __forceinline__ uint32_t sel32(uint32_t mask, uint32_t if_set, uint32_t if_clear) {
-    return (if_set & mask) | (if_clear & ~mask);
+    uint32_t r;  // truth table 0xca: mask ? if_set : if_clear, bit by bit
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(mask), "v"(if_set), "v"(if_clear));
+    return r;
 }
 
 __device__ __forceinline__ Fe fe_zero() {

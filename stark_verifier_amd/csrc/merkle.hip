@@ -42,7 +42,9 @@ __device__ __forceinline__ uint32_t leaf_word(const uint8_t* first, const uint8_
 
 // Lane-wise select through a 0 / 0xFFFFFFFF mask (one v_bitop3_b32).
 __device__ __forceinline__ uint32_t pick(uint32_t mask, uint32_t if_set, uint32_t if_clear) {
-    return (if_set & mask) | (if_clear & ~mask);
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(mask), "v"(if_set), "v"(if_clear));
+    return r;
 }
 
 template <bool VS32>
