@@ -47,6 +47,18 @@ __device__ __forceinline__ uint32_t pick(uint32_t mask, uint32_t if_set, uint32_
     return r;
 }
 
+#ifdef STARKHIP_STAMPS
+// timing instrumentation (debug builds only): lane 0 of every workgroup records the 100 MHz wall clock when it
+// starts, after the leaf hash and when it ends, with the compute unit it ran on
+__device__ unsigned long long g_mstamps[16384][4];
+#define MSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_mstamps[blockIdx.x][k] = wall_clock64(); } while (0)
+extern "C" int stark_debug_read_merkle_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mstamps), sizeof(g_mstamps));
+}
+#else
+#define MSTAMP(k) do {} while (0)
+#endif
+
 template <bool VS32>
 __global__ void __launch_bounds__(256)
 merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restrict__ siblings, uint32_t value_size,
@@ -56,6 +68,7 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
                      uint32_t* __restrict__ digests) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    MSTAMP(0);
 
     // permute_4_index with L = 2^(w+1): ld4 = 2^(w-1)
     uint32_t a = indices[i];
@@ -100,6 +113,7 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
         }
     }
 
+    MSTAMP(1);
     // ---- levels 1..w: one compression each ----
     uint32_t pos = idx >> 1;
     for (uint32_t l = 0; l < num_witnesses; l++) {
@@ -125,6 +139,14 @@ merkle_verify_kernel(const uint8_t* __restrict__ values, const uint8_t* __restri
 #pragma unroll
     for (int j = 0; j < 8; j++) diff |= h[j] ^ rt[j];
     accept[i] = diff == 0 ? 1 : 0;
+    MSTAMP(2);
+#ifdef STARKHIP_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_mstamps[blockIdx.x][3] = hw;
+    }
+#endif
     if (digests) {
         uint4* d = reinterpret_cast<uint4*>(digests) + 2 * i;
         d[0] = make_uint4(h[0], h[1], h[2], h[3]);
