@@ -55,12 +55,14 @@ def test_device_prover_reproduces_the_reference_fixture():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps,n_const", [(16, 4), (64, 16), (256, 64), (1024, 1024), (2048, 2)])
+@pytest.mark.parametrize("steps,n_const", [(16, 4), (64, 16), (256, 64), (1024, 1024), (2048, 2), (32768, 64)])
 def test_device_prover_matches_oracle_small(steps, n_const):
     from stark_verifier_amd import prover
     rng = np.random.default_rng(steps)
     consts = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(n_const)]
     inputs = [0, 1, P - 1, P + 5, (1 << 256) - 1] + [int.from_bytes(rng.bytes(32), "little") for _ in range(3)]
+    if steps > 8192:
+        inputs = inputs[3:5]          # the oracle needs seconds per proof at this size (7 FRI layers, 2^18 points)
     proofs, outs = prover.mk_mimc_proofs(inputs, steps, consts)
     for x, pf, o in zip(inputs, proofs, outs):
         want, wout = oprover.mk_mimc_proof(x % P, steps, consts)
