@@ -856,9 +856,9 @@ extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs,
             rest.push_back(i);
         }
     }
-    // descriptors and lanes take about 83 KB per proof: chunks of at most 2^16 proofs
-    for (size_t k0 = 0; k0 < who.size(); k0 += 65535) {
-        const size_t mc = std::min<size_t>(65535, who.size() - k0);
+    // descriptors and lanes take about 83 KB per proof (kept by the context between calls): chunks of 2^14 proofs
+    for (size_t k0 = 0; k0 < who.size(); k0 += 16384) {
+        const size_t mc = std::min<size_t>(16384, who.size() - k0);
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t o_who = up(8 * mc), o_io = o_who + up(4 * mc);
         uint8_t* d = nullptr;

@@ -161,11 +161,16 @@ struct DevTemplate : CtxAttachment {
     TCon* con = nullptr;
     TWord* words = nullptr;
     uint32_t n_words = 0;
+    // grow-only device buffers kept across calls: [0] descriptors, lanes and verdicts; [1] an uploaded chunk
+    uint8_t* buf[2] = {nullptr, nullptr};
+    size_t buf_bytes[2] = {0, 0};
     ~DevTemplate() override {
         (void)hipFree(branches);
         (void)hipFree(fri);
         (void)hipFree(con);
         (void)hipFree(words);
+        (void)hipFree(buf[0]);
+        (void)hipFree(buf[1]);
     }
 };
 constexpr int FAST_SLOT = 1;
@@ -396,6 +401,20 @@ static int get_dev_template(stark_ctx* ctx, DevTemplate** out) {
     return STARK_OK;
 }
 
+// the kept buffer `which`, at least `need` bytes (the stream is drained before a smaller one is released)
+static int kept_buffer(stark_ctx* ctx, DevTemplate* D, int which, size_t need, uint8_t** out) {
+    if (D->buf_bytes[which] < need) {
+        F_TRY(hipStreamSynchronize((hipStream_t)stark_ctx_stream(ctx)));
+        if (D->buf[which]) F_TRY(hipFree(D->buf[which]));
+        D->buf[which] = nullptr;
+        D->buf_bytes[which] = 0;
+        F_TRY(hipMalloc((void**)&D->buf[which], need));
+        D->buf_bytes[which] = need;
+    }
+    *out = D->buf[which];
+    return STARK_OK;
+}
+
 // Everything resident: d_blob holds the proofs, d_base[i] the offset of canonical proof i inside it (a multiple of 4),
 // d_io per proof 8 + 8 canonical limbs (input, slope). status_out (host) as the general path would set it.
 int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io, size_t mc,
@@ -420,11 +439,7 @@ int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* 
                  o_con = take(sizeof(ConstraintLane) * (size_t)SPOT * m), o_kk = take(CHECK_PROOF_BYTES * (size_t)m),
                  o_chk = take((size_t)(N_FRI + SPOT) * m), o_st = take(m);
     uint8_t* d = nullptr;
-    F_TRY(hipMalloc((void**)&d, o));
-    struct Free {
-        uint8_t* p;
-        ~Free() { (void)hipFree(p); }
-    } guard{d};
+    if ((rc = kept_buffer(ctx, D, 0, o, &d)) != STARK_OK) return rc;
     uint32_t* samples = (uint32_t*)(d + o_samp);
     SeedOffs so;
     memcpy(so.off, T.seed_off, sizeof so.off);
@@ -467,12 +482,11 @@ int fast_verify(stark_ctx* ctx, const uint8_t* chunk, size_t chunk_len, const ui
     hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_base = up(chunk_len + 16), o_io = o_base + up(8 * mc);
+    DevTemplate* D;
+    int rc = get_dev_template(ctx, &D);
+    if (rc != STARK_OK) return rc;
     uint8_t* d = nullptr;
-    F_TRY(hipMalloc((void**)&d, o_io + up(64 * mc)));
-    struct Free {
-        uint8_t* p;
-        ~Free() { (void)hipFree(p); }
-    } guard{d};
+    if ((rc = kept_buffer(ctx, D, 1, o_io + up(64 * mc), &d)) != STARK_OK) return rc;
     F_TRY(copy_h2d(ctx, d, chunk, chunk_len, st));
     F_TRY(hipMemcpyAsync(d + o_base, bases, 8 * mc, hipMemcpyHostToDevice, st));
     F_TRY(hipMemcpyAsync(d + o_io, io, 64 * mc, hipMemcpyHostToDevice, st));
