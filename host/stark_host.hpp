@@ -177,6 +177,15 @@ inline std::vector<bool> verify_mimc_proofs(Context& c, const std::vector<U256>&
     return std::vector<bool>(accept.begin(), accept.end());
 }
 
+// utils::mimc(input, steps, round_constants, modulus) (reference src/utils.rs:8-16) for many inputs at once.
+inline std::vector<U256> mimc(Context& c, const std::vector<U256>& inputs, size_t steps, const std::vector<U256>& round_constants) {
+    std::vector<U256> out(inputs.size());
+    c.check(stark_mimc_batch(c.get(), inputs.empty() ? nullptr : inputs[0].data(), inputs.size(), steps,
+                             round_constants.empty() ? nullptr : round_constants[0].data(), round_constants.size(),
+                             out.empty() ? nullptr : out[0].data()));
+    return out;
+}
+
 // Proof generation (the reference's proofs come from an external program, README.md:9): one serialized proof per
 // input, in the format deserializer::from_bytes reads; outputs[i] = mimc(inputs[i], num_steps, round_constants)
 // (src/utils.rs:8-16), the value verify_mimc_proof is called with.

@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
         bad[good.size() / 3] ^= 0x20;
         U256 inp{3, 0, 0, 0, 0, 0, 0, 0};
         U256 out = from_be_hex("d2874ff35f56a2f7f5e0cfc8c4e6ae570f3636219c6a3bc8810deec3361ad858");
+        if (mimc(ctx, {inp}, 8192, consts)[0] != out) { printf("FAIL: mimc(3, 8192) known answer\n"); return 1; }
         std::vector<uint8_t> status;
         std::vector<bool> acc = verify_mimc_proofs(ctx, inp, 8192, consts, out, {good, bad, good}, &status);
         if (!(acc[0] && !acc[1] && acc[2])) { printf("FAIL: batch accept bits %d %d %d\n", (int)acc[0], (int)acc[1], (int)acc[2]); return 1; }

@@ -227,6 +227,19 @@ int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs, uint64_t p
  * num_steps 8192 and the 64 constants of src/main.rs:209-212 the output equals the reference's proof.bin.
  * ------------------------------------------------------------------------------------- */
 
+/*
+ * utils::mimc(input, steps, round_constants, modulus) (reference src/utils.rs:8-16; called at src/main.rs:216 to get the
+ * public output the verifier is given) for n inputs at once: steps - 1 rounds of x -> x^3 + round_constants[i mod
+ * n_constants] mod p. inputs / round_constants may be any 256-bit values; outputs are canonical. STARK_ERR_INVALID where
+ * the reference's loop bound underflows (steps == 0) or its index divides by zero (no constants and steps > 1).
+ * Host version: host pointers, returns when outputs are written. Device version: device pointers (16-byte aligned),
+ * queued on `stream` (NULL = the context's stream).
+ */
+int stark_mimc_batch(stark_ctx* ctx, const uint32_t* inputs, size_t n, uint64_t steps, const uint32_t* round_constants,
+                     size_t n_constants, uint32_t* outputs);
+int stark_mimc_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, uint64_t steps, const void* d_round_constants,
+                         size_t n_constants, void* d_outputs, void* stream);
+
 /* Bytes of one serialized proof for these parameters (566,508 for 8192 steps); 0 if they are rejected:
  * num_steps a power of two in [16, 2^17], n_constants a power of two <= num_steps. */
 size_t stark_mimc_proof_size(uint64_t num_steps, size_t n_constants);

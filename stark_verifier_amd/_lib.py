@@ -31,7 +31,7 @@ EXPORTS = [
     "stark_fill_random_field_dev", "stark_twiddle_mul_dev", "stark_permute3_dev",
     "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
     "stark_merkle_build", "stark_merkle_build_dev",
-    "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev",
+    "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev", "stark_mimc_batch", "stark_mimc_batch_dev",
 ]
 
 
@@ -103,6 +103,10 @@ def load() -> ctypes.CDLL:
     L.stark_merkle_build.restype = i32
     L.stark_merkle_build_dev.argtypes = [vp, vp, ctypes.c_uint, vp]
     L.stark_merkle_build_dev.restype = i32
+    L.stark_mimc_batch.argtypes = [vp, vp, sz, u64, vp, sz, vp]
+    L.stark_mimc_batch.restype = i32
+    L.stark_mimc_batch_dev.argtypes = [vp, vp, sz, u64, vp, sz, vp, vp]
+    L.stark_mimc_batch_dev.restype = i32
     L.stark_mimc_proof_size.argtypes = [u64, sz]
     L.stark_mimc_proof_size.restype = sz
     L.stark_mimc_prove_batch.argtypes = [vp, vp, sz, u64, vp, sz, vp, vp]

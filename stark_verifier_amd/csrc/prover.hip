@@ -107,6 +107,23 @@ trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, co
     store_limbs(io + 16 * (size_t)pr + 8, mul_t(f29_sub(x, inp), limbs_arg(D.inv_last_m1)));
 }
 
+// ---- utils::mimc (reference src/utils.rs:8-16) for many inputs: steps - 1 rounds of x -> x^3 + k[i mod len]; lane = input ----
+__global__ void __launch_bounds__(64)
+mimc_kernel(const uint32_t* __restrict__ inputs, size_t n, uint64_t steps, const uint32_t* __restrict__ consts,
+            uint32_t n_consts, uint32_t* __restrict__ outputs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    F29 x = norm(load_limbs(inputs + 8 * t));
+    uint32_t ci = 0;
+#pragma unroll 1
+    for (uint64_t i = 0; i + 1 < steps; i++) {
+        const F29 c = norm(load_limbs(consts + 8 * (size_t)ci));
+        x = norm(f29_add(mul_t(mul_t(x, x), x), c));
+        ci = ci + 1 == n_consts ? 0 : ci + 1;
+    }
+    store_limbs(outputs + 8 * t, x);
+}
+
 // ---- D, B and the 96-byte leaves: lane = (proof, point) ----
 __global__ void __launch_bounds__(256) columns_kernel(Dev D) {
     const uint32_t pr = blockIdx.y, N = 1u << D.log_n;
@@ -754,6 +771,50 @@ using namespace starkhip::prover;
 #define STARK_CATCH                                              \
     catch (const std::bad_alloc&) { return STARK_ERR_NOMEM; }    \
     catch (...) { return STARK_ERR_HIP; }
+
+extern "C" int stark_mimc_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, uint64_t steps, const void* d_round_constants,
+                                    size_t n_constants, void* d_outputs, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    // the reference's loop bound is steps - 1 on an unsigned value and it indexes i % len
+    if (steps == 0 || (steps > 1 && n_constants == 0) || n_constants > 0xFFFFFFFFull) {
+        ctx_set_error(ctx, "steps must be at least 1 and, above 1, there must be round constants");
+        return STARK_ERR_INVALID;
+    }
+    if (n == 0) return STARK_OK;
+    if (!d_inputs || !d_outputs || (steps > 1 && !d_round_constants)) return STARK_ERR_INVALID;
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)stark_ctx_stream(ctx);
+    hipLaunchKernelGGL(mimc_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_inputs, n, steps,
+                       (const uint32_t*)d_round_constants, (uint32_t)n_constants, (uint32_t*)d_outputs);
+    P_TRY(hipGetLastError());
+    return STARK_OK;
+} STARK_CATCH
+
+extern "C" int stark_mimc_batch(stark_ctx* ctx, const uint32_t* inputs, size_t n, uint64_t steps, const uint32_t* round_constants,
+                                size_t n_constants, uint32_t* outputs) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (steps == 0 || (steps > 1 && n_constants == 0) || n_constants > 0xFFFFFFFFull) {
+        ctx_set_error(ctx, "steps must be at least 1 and, above 1, there must be round constants");
+        return STARK_ERR_INVALID;
+    }
+    if (n == 0) return STARK_OK;
+    if (!inputs || !outputs || (steps > 1 && !round_constants)) return STARK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_out = up(32 * n), o_c = 2 * o_out;
+    uint8_t* d = nullptr;
+    P_TRY(hipMalloc((void**)&d, o_c + up(32 * n_constants + 32)));
+    struct Free {
+        uint8_t* p;
+        ~Free() { (void)hipFree(p); }
+    } guard{d};
+    P_TRY(hipMemcpyAsync(d, inputs, 32 * n, hipMemcpyHostToDevice, st));
+    if (n_constants) P_TRY(hipMemcpyAsync(d + o_c, round_constants, 32 * n_constants, hipMemcpyHostToDevice, st));
+    int rc = stark_mimc_batch_dev(ctx, d, n, steps, d + o_c, n_constants, d + o_out, st);
+    if (rc != STARK_OK) return rc;
+    P_TRY(hipMemcpyAsync(outputs, d + o_out, 32 * n, hipMemcpyDeviceToHost, st));
+    P_TRY(hipStreamSynchronize(st));
+    return STARK_OK;
+} STARK_CATCH
 
 extern "C" size_t stark_mimc_proof_size(uint64_t num_steps, size_t n_constants) {
     try {

@@ -11,6 +11,19 @@ from . import _lib
 from .fft import MODULUS, _limbs
 
 
+def mimc(inputs: Sequence[int], steps: int, round_constants: Sequence[int], ctx: _lib.Context | None = None) -> List[int]:
+    """utils::mimc (reference src/utils.rs:8-16) for many inputs: steps - 1 rounds of x -> x^3 + k[i mod len] mod p."""
+    ctx = ctx or _lib.default_context()
+    n = len(inputs)
+    inp = np.ascontiguousarray(np.concatenate([_limbs(int(x) % (1 << 256)) for x in inputs])) if n else np.zeros(8, dtype=np.uint32)
+    rc = (np.ascontiguousarray(np.concatenate([_limbs(int(c) % (1 << 256)) for c in round_constants]))
+          if len(round_constants) else np.zeros(8, dtype=np.uint32))
+    out = np.empty(8 * max(n, 1), dtype=np.uint32)
+    ctx.check(ctx.lib.stark_mimc_batch(ctx.handle, inp.ctypes.data, n, steps, rc.ctypes.data if len(round_constants) else None,
+                                       len(round_constants), out.ctypes.data))
+    return [int.from_bytes(out[8 * i:8 * i + 8].astype("<u4").tobytes(), "little") for i in range(n)]
+
+
 def mimc_proof_size(num_steps: int, n_constants: int) -> int:
     """Bytes of one serialized proof, 0 when the parameters are rejected."""
     return int(_lib.load().stark_mimc_proof_size(num_steps, n_constants))

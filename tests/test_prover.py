@@ -161,3 +161,21 @@ def test_prove_and_verify_without_leaving_the_device(monkeypatch):
     monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
     a_g, s_g = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in2.data_ptr(), 8192, consts, d_out.data_ptr())
     assert np.array_equal(a, a_g) and np.array_equal(s, s_g)
+
+
+@pytest.mark.gpu
+def test_mimc_batch_matches_the_reference_function():
+    """utils::mimc for many inputs: any step count >= 1 and any number of constants (the reference indexes i % len)."""
+    from stark_verifier_amd import _lib, prover
+    rng = np.random.default_rng(12)
+    inputs = [0, 1, 3, P - 1, P, (1 << 256) - 1] + [int.from_bytes(rng.bytes(32), "little") for _ in range(70)]
+    for steps, n_const in ((1, 0), (1, 3), (2, 1), (3, 2), (100, 3), (257, 64), (8192, 64)):
+        consts = [int.from_bytes(rng.bytes(32), "little") for _ in range(n_const)] if steps != 8192 else rv.mimc_constants()
+        got = prover.mimc(inputs, steps, consts)
+        for x, g in zip(inputs, got):
+            assert g == rv.mimc(x % P, steps, [c % P for c in consts]) % P, (steps, n_const, x)
+    assert prover.mimc([], 10, [1]) == []
+    with pytest.raises(_lib.InvalidArgument):
+        prover.mimc([1], 0, [1])
+    with pytest.raises(_lib.InvalidArgument):
+        prover.mimc([1], 5, [])
