@@ -91,3 +91,19 @@ def verify_mimc_batch_sharded(proofs: Sequence[bytes], inp: int, num_steps: int,
     fn = verify or (lambda blobs: verify_mimc_batch(blobs, inp, num_steps, round_constants, output, ctx))
     accept, status = fn(list(proofs[lo:hi]))
     return gather_accept_bits(accept, len(proofs)), gather_accept_bits(status, len(proofs))
+
+
+def verify_mimc_batch_io_sharded(proofs: Sequence[bytes], inputs: Sequence[int], num_steps: int, round_constants: Sequence[int],
+                                 outputs: Sequence[int], ctx: _lib.Context | None = None, verify=None):
+    """verify_mimc_batch_io split over the ranks of the default process group: rank r verifies the contiguous slice
+    `shard_range(len(proofs), r, world)` with its own inputs and outputs, and the per-proof flags are gathered (the only
+    exchange). `verify(blobs, inputs, outputs)` replaces the device call (CPU tests of the partitioning)."""
+    from .sharding import gather_accept_bits, shard_range
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    lo, hi = shard_range(len(proofs), rank, world)
+    fn = verify or (lambda b, i, o: verify_mimc_batch_io(b, i, num_steps, round_constants, o, ctx))
+    accept, status = fn(list(proofs[lo:hi]), list(inputs[lo:hi]), list(outputs[lo:hi]))
+    return gather_accept_bits(accept, len(proofs)), gather_accept_bits(status, len(proofs))

@@ -59,3 +59,20 @@ def mk_mimc_proofs_dev(d_inputs: int, n: int, num_steps: int, round_constants: S
     rc = np.ascontiguousarray(np.concatenate([_limbs(int(c) % MODULUS) for c in round_constants]))
     ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inputs, n, num_steps, rc.ctypes.data, len(round_constants),
                                                  d_proofs, proof_stride, d_outputs, stream))
+
+
+def mk_mimc_proofs_sharded(inputs: Sequence[int], num_steps: int, round_constants: Sequence[int],
+                           ctx: _lib.Context | None = None, prove=None) -> Tuple[List[bytes], List[int], Tuple[int, int]]:
+    """Proof generation split over the ranks of the default process group (one process per GPU): proofs are independent,
+    so rank r makes the proofs of the contiguous slice `shard_range(len(inputs), r, world)` and nothing is exchanged (a
+    proof is 0.5 MB; the caller gathers them if it wants them in one place). Returns (proofs, outputs, (lo, hi)) for this
+    rank's slice. `prove(inputs)` replaces the device call (CPU tests of the partitioning)."""
+    from .sharding import shard_range
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    lo, hi = shard_range(len(inputs), rank, world)
+    fn = prove or (lambda xs: mk_mimc_proofs(xs, num_steps, round_constants, ctx))
+    proofs, outs = fn(list(inputs[lo:hi]))
+    return proofs, outs, (lo, hi)

@@ -123,6 +123,19 @@ def fake(blobs):   # stands in for the device call: accepts even-valued proofs, 
 acc, st = batch.verify_mimc_batch_sharded(proofs, 3, 8192, [1], 5, verify=fake)
 assert list(acc) == [1, 0] * 5 + [1] and list(st) == list(range(11))
 assert len(seen) in (5, 6) and all(p in proofs for p in seen)   # each rank saw only its slice
+# one (input, output) pair per proof, and proof generation: the same contiguous slices, nothing else exchanged
+from stark_verifier_amd import prover
+ins, outs = list(range(100, 111)), list(range(200, 211))
+def fake_io(blobs, i, o):
+    assert len(blobs) == len(i) == len(o) and all(b[0] + 100 == x and b[0] + 200 == y for b, x, y in zip(blobs, i, o))
+    return fake(blobs)
+acc, st = batch.verify_mimc_batch_io_sharded(proofs, ins, 8192, [1], outs, verify=fake_io)
+assert list(acc) == [1, 0] * 5 + [1] and list(st) == list(range(11))
+made, mouts, (lo, hi) = prover.mk_mimc_proofs_sharded(ins, 8192, [1], prove=lambda xs: ([bytes([x - 100]) for x in xs], [x + 1 for x in xs]))
+assert made == [bytes([k]) for k in range(lo, hi)] and mouts == [101 + k for k in range(lo, hi)]
+sizes = [None, None]
+dist.all_gather_object(sizes, (lo, hi))
+assert sizes[0][0] == 0 and sizes[0][1] == sizes[1][0] and sizes[1][1] == 11
 if rank == 0:
     print("ok")
 dist.destroy_process_group()
