@@ -562,6 +562,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                        const uint32_t* output, size_t io_stride, uint64_t num_steps, const uint32_t* round_constants,
                        size_t n_constants, uint8_t* accept, uint8_t* status) {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
     if (((n_proofs || !io_stride) && (!inp || !output)) || (n_constants && !round_constants)) return STARK_ERR_INVALID;
     for (size_t i = 0; i < n_proofs; i++)
@@ -825,6 +826,7 @@ extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs,
                                            const void* d_inputs, uint64_t num_steps, const uint32_t* round_constants,
                                            size_t n_constants, const void* d_outputs, uint8_t* accept, uint8_t* status) try {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (n_proofs && (!d_proofs || !d_inputs || !d_outputs || !accept)) return STARK_ERR_INVALID;
     if (n_constants && !round_constants) return STARK_ERR_INVALID;
     if (n_proofs == 0) return STARK_OK;

@@ -157,6 +157,7 @@ CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot) {
 void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a) {
     if (ctx && slot >= 0 && slot < CTX_SLOTS) ctx->attach[slot].reset(a);
 }
+hipError_t ctx_make_current(stark_ctx* ctx) { return ctx ? hipSetDevice(ctx->device) : hipErrorInvalidValue; }
 void ctx_set_error(stark_ctx* ctx, const char* text) {
     if (ctx) ctx->err = text ? text : "";
 }

@@ -18,6 +18,8 @@ constexpr int CTX_SLOTS = 4;
 CtxAttachment* ctx_get_attachment(stark_ctx* ctx, int slot);
 void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a);
 void ctx_set_error(stark_ctx* ctx, const char* text);
+// makes the context's device the calling thread's current device (every entry point does this first)
+hipError_t ctx_make_current(stark_ctx* ctx);
 
 // Copies between ordinary (pageable) host memory and the device through two pinned staging buffers of the context:
 // host threads fill or drain one while the DMA engine moves the other (about twice the rate of a direct copy from

@@ -775,6 +775,7 @@ using namespace starkhip::prover;
 extern "C" int stark_mimc_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, uint64_t steps, const void* d_round_constants,
                                     size_t n_constants, void* d_outputs, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     // the reference's loop bound is steps - 1 on an unsigned value and it indexes i % len
     if (steps == 0 || (steps > 1 && n_constants == 0) || n_constants > 0xFFFFFFFFull) {
         ctx_set_error(ctx, "steps must be at least 1 and, above 1, there must be round constants");
@@ -792,6 +793,7 @@ extern "C" int stark_mimc_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t
 extern "C" int stark_mimc_batch(stark_ctx* ctx, const uint32_t* inputs, size_t n, uint64_t steps, const uint32_t* round_constants,
                                 size_t n_constants, uint32_t* outputs) try {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (steps == 0 || (steps > 1 && n_constants == 0) || n_constants > 0xFFFFFFFFull) {
         ctx_set_error(ctx, "steps must be at least 1 and, above 1, there must be round constants");
         return STARK_ERR_INVALID;
@@ -831,6 +833,7 @@ extern "C" int stark_mimc_prove_batch_dev(stark_ctx* ctx, const void* d_inputs, 
                                           const uint32_t* round_constants, size_t n_constants, void* d_proofs,
                                           uint64_t proof_stride, void* d_outputs, void* stream) try {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (!round_constants || (n && (!d_inputs || !d_proofs || !d_outputs))) return STARK_ERR_INVALID;
     if (!params_ok(num_steps, n_constants)) {
         ctx_set_error(ctx, "num_steps must be a power of two in [16, 2^17] and n_constants a power of two <= num_steps");
@@ -853,6 +856,7 @@ extern "C" int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, si
                                       const uint32_t* round_constants, size_t n_constants, uint8_t* proofs,
                                       uint32_t* outputs) try {
     if (!ctx) return STARK_ERR_INVALID;
+    if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (!round_constants || (n && (!inputs || !proofs || !outputs))) return STARK_ERR_INVALID;
     if (!params_ok(num_steps, n_constants)) {
         ctx_set_error(ctx, "num_steps must be a power of two in [16, 2^17] and n_constants a power of two <= num_steps");
