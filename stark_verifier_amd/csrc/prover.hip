@@ -92,17 +92,20 @@ trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, co
              Dev D) {
     const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= n) return;
-    F29 x = norm(load_limbs(inputs + 8 * (size_t)pr));
+    // the value is carried both ways: canonical 8 x 32-bit for the store, nine limbs for the arithmetic
+    Fe xe = f29_to_fe(load_limbs(inputs + 8 * (size_t)pr));
+    F29 x = f29_from_fe(xe);
     const F29 inp = x;
     uint32_t* row = trace + 8 * (size_t)pr * steps;
 #pragma unroll 1
     for (uint32_t i = 0; i + 1 < steps; i++) {
-        store_limbs(row + 8 * (size_t)i, x);
+        fe_store(row + 8 * (size_t)i, xe);
         const F29 c = load_limbs(consts + 8 * (i & cmask));
-        x = norm(f29_add(mul_t(mul_t(x, x), x), c));
+        xe = f29_to_fe(f29_add(mul_t(mul_t(x, x), x), c));
+        x = f29_from_fe(xe);
     }
-    store_limbs(row + 8 * (size_t)(steps - 1), x);
-    store_limbs(outputs + 8 * (size_t)pr, x);
+    fe_store(row + 8 * (size_t)(steps - 1), xe);
+    fe_store(outputs + 8 * (size_t)pr, xe);
     store_limbs(io + 16 * (size_t)pr, inp);
     store_limbs(io + 16 * (size_t)pr + 8, mul_t(f29_sub(x, inp), limbs_arg(D.inv_last_m1)));
 }

@@ -12,7 +12,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 n_ntt = n_mk = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:   # a line every half minute: a silent run is taken to be hung
+        print("... %d s left" % int(t_end - time.time()), flush=True)
+        t_say = time.time() + 30
     if rng.random() < 0.6:
         log_n = int(rng.integers(0, 17))
         n = 1 << log_n

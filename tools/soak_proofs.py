@@ -22,7 +22,11 @@ t_end = time.time() + budget
 consts8192 = [(i ** 7) ^ 42 for i in range(64)]
 size = prover.mimc_proof_size(8192, 64)
 n_small = n_verify = n_damaged = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:   # a line every half minute: a silent run is taken to be hung
+        print("... %d s left" % int(t_end - time.time()), flush=True)
+        t_say = time.time() + 30
     if rng.random() < 0.5:
         steps = 1 << int(rng.integers(4, 12))
         n_const = 1 << int(rng.integers(0, int(np.log2(steps)) + 1))
