@@ -224,68 +224,74 @@ def main():
     # ---- region C: end-to-end verification of distinct synthetic proofs (host buffers in, verdicts out) ----
     batch_res, batch_ok = None, True
     if args.proofs > 0:
-        del x, y
-        torch.cuda.empty_cache()
-        from stark_verifier_amd.fft import _limbs
-        NP, steps_mimc = args.proofs, 8192
-        consts = [(i ** 7) ^ 42 for i in range(64)]   # reference src/main.rs:209-212
-        rcs = np.ascontiguousarray(np.concatenate([_limbs(c) for c in consts]))
-        size = int(ctx.lib.stark_mimc_proof_size(steps_mimc, len(consts)))
-        rng = np.random.default_rng(SEED + 9 + rank)
-        inp = np.frombuffer(rng.bytes(32 * NP), dtype=np.uint32).copy()
-        inp[7::8] >>= 1                                # below 2^255 < p: canonical inputs
-        d_inp = torch.from_numpy(inp.view(np.int32)).to(device)
-        d_outp = torch.empty(8 * NP, dtype=torch.int32, device=device)
-        d_proofs = torch.empty(NP * size, dtype=torch.uint8, device=device)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inp.data_ptr(), NP, steps_mimc, rcs.ctypes.data, len(consts),
-                                                     d_proofs.data_ptr(), size, d_outp.data_ptr(), None))
-        ctx.synchronize()
-        t_prove_first = time.perf_counter() - t0     # includes the prover's tables and buffers
-        t0 = time.perf_counter()
-        ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inp.data_ptr(), NP, steps_mimc, rcs.ctypes.data, len(consts),
-                                                     d_proofs.data_ptr(), size, d_outp.data_ptr(), None))
-        ctx.synchronize()
-        t_prove = time.perf_counter() - t0
-        # every 100th proof gets one damaged byte inside its first column value
-        view = d_proofs.view(NP, size)
-        bad = torch.arange(7, NP, 100, device=device)
-        view[bad, 140] ^= 0x10
-        torch.cuda.synchronize()
-        expect_b = np.ones(NP, dtype=np.uint8)
-        expect_b[7::100] = 0
-        h_proofs = d_proofs.cpu().numpy()
-        h_out = d_outp.cpu().numpy().view(np.uint32)
-        offsets = np.arange(NP + 1, dtype=np.uint64) * np.uint64(size)
-        acc_b = np.zeros(NP, dtype=np.uint8)
-        st_b = np.zeros(NP, dtype=np.uint8)
+        try:
+            del x, y
+            torch.cuda.empty_cache()
+            from stark_verifier_amd.fft import _limbs
+            NP, steps_mimc = args.proofs, 8192
+            consts = [(i ** 7) ^ 42 for i in range(64)]   # reference src/main.rs:209-212
+            rcs = np.ascontiguousarray(np.concatenate([_limbs(c) for c in consts]))
+            size = int(ctx.lib.stark_mimc_proof_size(steps_mimc, len(consts)))
+            rng = np.random.default_rng(SEED + 9 + rank)
+            inp = np.frombuffer(rng.bytes(32 * NP), dtype=np.uint32).copy()
+            inp[7::8] >>= 1                                # below 2^255 < p: canonical inputs
+            d_inp = torch.from_numpy(inp.view(np.int32)).to(device)
+            d_outp = torch.empty(8 * NP, dtype=torch.int32, device=device)
+            d_proofs = torch.empty(NP * size, dtype=torch.uint8, device=device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inp.data_ptr(), NP, steps_mimc, rcs.ctypes.data, len(consts),
+                                                         d_proofs.data_ptr(), size, d_outp.data_ptr(), None))
+            ctx.synchronize()
+            t_prove_first = time.perf_counter() - t0     # includes the prover's tables and buffers
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.stark_mimc_prove_batch_dev(ctx.handle, d_inp.data_ptr(), NP, steps_mimc, rcs.ctypes.data, len(consts),
+                                                         d_proofs.data_ptr(), size, d_outp.data_ptr(), None))
+            ctx.synchronize()
+            t_prove = time.perf_counter() - t0
+            # every 100th proof gets one damaged byte inside its first column value
+            view = d_proofs.view(NP, size)
+            bad = torch.arange(7, NP, 100, device=device)
+            view[bad, 140] ^= 0x10
+            torch.cuda.synchronize()
+            expect_b = np.ones(NP, dtype=np.uint8)
+            expect_b[7::100] = 0
+            h_proofs = d_proofs.cpu().numpy()
+            h_out = d_outp.cpu().numpy().view(np.uint32)
+            offsets = np.arange(NP + 1, dtype=np.uint64) * np.uint64(size)
+            acc_b = np.zeros(NP, dtype=np.uint8)
+            st_b = np.zeros(NP, dtype=np.uint8)
 
-        def batch_step():
-            ctx.check(ctx.lib.stark_mimc_verify_batch_io(ctx.handle, h_proofs.ctypes.data, offsets.ctypes.data, NP, inp.ctypes.data,
-                                                         steps_mimc, rcs.ctypes.data, len(consts), h_out.ctypes.data,
-                                                         acc_b.ctypes.data, st_b.ctypes.data))
+            def batch_step():
+                ctx.check(ctx.lib.stark_mimc_verify_batch_io(ctx.handle, h_proofs.ctypes.data, offsets.ctypes.data, NP, inp.ctypes.data,
+                                                             steps_mimc, rcs.ctypes.data, len(consts), h_out.ctypes.data,
+                                                             acc_b.ctypes.data, st_b.ctypes.data))
 
-        def resident_step():
-            ctx.check(ctx.lib.stark_mimc_verify_batch_dev(ctx.handle, d_proofs.data_ptr(), size, NP, d_inp.data_ptr(), steps_mimc,
-                                                          rcs.ctypes.data, len(consts), d_outp.data_ptr(), acc_b.ctypes.data,
-                                                          st_b.ctypes.data))
+            def resident_step():
+                ctx.check(ctx.lib.stark_mimc_verify_batch_dev(ctx.handle, d_proofs.data_ptr(), size, NP, d_inp.data_ptr(), steps_mimc,
+                                                              rcs.ctypes.data, len(consts), d_outp.data_ptr(), acc_b.ctypes.data,
+                                                              st_b.ctypes.data))
 
-        bw = min(args.warmup, 1)
-        dt_b, _ = timed_region(batch_step, args.steps, bw, world, coll_device)
-        batch_ok = bool(np.array_equal(acc_b, expect_b))
-        acc_b[:] = 0
-        dt_r, _ = timed_region(resident_step, args.steps, bw, world, coll_device)
-        batch_ok = batch_ok and bool(np.array_equal(acc_b, expect_b))
-        batch_res = {
-            "metric": "MiMC STARK proofs verified/sec (8192 steps, %d distinct synthetic proofs per GPU per step, 1 %% damaged)" % NP,
-            "value": world * NP * args.steps / dt_b, "unit": "proofs/s", "ms_per_step": dt_b / args.steps * 1e3,
-            "path": "host buffers in (structure check on host threads, upload, sampling + 1,240 branches + field checks per proof on the device), verdicts out",
-            "branches_per_s": 1240.0 * world * NP * args.steps / dt_b,
-            "device_resident_value": world * NP * args.steps / dt_r, "device_resident_ms_per_step": dt_r / args.steps * 1e3,
-            "proofs_made_on_device_per_s": NP / t_prove, "first_prover_call_s": t_prove_first,
-            "proof_bytes": size, "accept_vector_as_constructed": batch_ok,
-        }
+            bw = min(args.warmup, 1)
+            dt_b, _ = timed_region(batch_step, args.steps, bw, world, coll_device)
+            batch_ok = bool(np.array_equal(acc_b, expect_b))
+            acc_b[:] = 0
+            dt_r, _ = timed_region(resident_step, args.steps, bw, world, coll_device)
+            batch_ok = batch_ok and bool(np.array_equal(acc_b, expect_b))
+            batch_res = {
+                "metric": "MiMC STARK proofs verified/sec (8192 steps, %d distinct synthetic proofs per GPU per step, 1 %% damaged)" % NP,
+                "value": world * NP * args.steps / dt_b, "unit": "proofs/s", "ms_per_step": dt_b / args.steps * 1e3,
+                "path": "host buffers in (structure check on host threads, upload, sampling + 1,240 branches + field checks per proof on the device), verdicts out",
+                "branches_per_s": 1240.0 * world * NP * args.steps / dt_b,
+                "device_resident_value": world * NP * args.steps / dt_r, "device_resident_ms_per_step": dt_r / args.steps * 1e3,
+                "proofs_made_on_device_per_s": NP / t_prove, "first_prover_call_s": t_prove_first,
+                "proof_bytes": size, "accept_vector_as_constructed": batch_ok,
+            }
+        except Exception as exc:  # the headline regions above stand on their own: report, do not lose the line
+            if world > 1:
+                raise             # the other ranks wait in this region's barriers: fail fast instead of hanging them
+            batch_res = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            print("batch region failed: %r" % (exc,), file=sys.stderr)
 
     ok = torch.tensor([int(roundtrip_ok and accept_ok and batch_ok)], device=coll_device)
     if world > 1:
@@ -346,7 +352,8 @@ def main():
         }
         if batch_res is not None:
             out["batch_verify"] = batch_res
-            out["parity"]["batch_accept_vector_as_constructed"] = batch_ok
+            if "error" not in batch_res:
+                out["parity"]["batch_accept_vector_as_constructed"] = batch_ok
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(log_n, 50000, case)
         print(json.dumps(out))
