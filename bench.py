@@ -259,8 +259,9 @@ def main():
             t_prove = time.perf_counter() - t0
             # every 100th proof gets one damaged byte inside its first column value
             view = d_proofs.view(NP, size)
-            bad = torch.arange(7, NP, 100, device=device)
-            view[bad, 140] ^= 0x10
+            if NP > 7:
+                bad = torch.arange(7, NP, 100, device=device)
+                view[bad, 140] ^= 0x10
             torch.cuda.synchronize()
             expect_b = np.ones(NP, dtype=np.uint8)
             expect_b[7::100] = 0
