@@ -179,3 +179,32 @@ def test_mimc_batch_matches_the_reference_function():
         prover.mimc([1], 0, [1])
     with pytest.raises(_lib.InvalidArgument):
         prover.mimc([1], 5, [])
+
+
+@pytest.mark.gpu
+def test_device_resident_verifier_odd_strides_and_empty_batch():
+    """A stride that is not a multiple of 4 (or shorter than a proof) cannot take the in-place path: every proof is
+    copied out and parsed, with the same verdicts."""
+    import torch
+    from stark_verifier_amd import batch, prover
+    from stark_verifier_amd.fft import _limbs
+    consts = rv.mimc_constants()
+    inputs = [3, 9, 27]
+    proofs, outs = prover.mk_mimc_proofs(inputs, 8192, consts)
+    size = len(proofs[0])
+    d_in = torch.from_numpy(np.concatenate([_limbs(x) for x in inputs]).view(np.int32)).cuda()
+    d_out = torch.from_numpy(np.concatenate([_limbs(x) for x in outs]).view(np.int32)).cuda()
+    for stride in (size + 1, size + 2, size - 4):
+        host = np.zeros((3, stride), dtype=np.uint8)
+        for i, p in enumerate(proofs):
+            host[i, :min(size, stride)] = np.frombuffer(p, dtype=np.uint8)[:stride]
+        host[1, 3000] ^= 2
+        d = torch.from_numpy(host).cuda()
+        torch.cuda.synchronize()
+        a, s = batch.verify_mimc_batch_dev(d.data_ptr(), stride, 3, d_in.data_ptr(), 8192, consts, d_out.data_ptr())
+        if stride >= size:
+            assert a.tolist() == [1, 0, 1] and s[1] == 4, (stride, s.tolist())
+        else:
+            assert a.tolist() == [0, 0, 0] and set(s.tolist()) == {2}, (stride, s.tolist())   # truncated: parser error
+    a, s = batch.verify_mimc_batch_dev(0, size, 0, 0, 8192, consts, 0)
+    assert a.size == 0
