@@ -208,3 +208,23 @@ def test_device_resident_verifier_odd_strides_and_empty_batch():
             assert a.tolist() == [0, 0, 0] and set(s.tolist()) == {2}, (stride, s.tolist())   # truncated: parser error
     a, s = batch.verify_mimc_batch_dev(0, size, 0, 0, 8192, consts, 0)
     assert a.size == 0
+
+
+@pytest.mark.gpu
+def test_device_prover_dev_entry_point_checks_the_stride():
+    import torch
+    from stark_verifier_amd import _lib, prover
+    from stark_verifier_amd.fft import _limbs
+    consts = rv.mimc_constants()
+    size = prover.mimc_proof_size(8192, 64)
+    d_in = torch.from_numpy(_limbs(3).view(np.int32)).cuda()
+    d_out = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_proofs = torch.zeros(size + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for stride in (size - 4, size + 2):
+        with pytest.raises(_lib.InvalidArgument):
+            prover.mk_mimc_proofs_dev(d_in.data_ptr(), 1, 8192, consts, d_proofs.data_ptr(), stride, d_out.data_ptr())
+    prover.mk_mimc_proofs_dev(d_in.data_ptr(), 1, 8192, consts, d_proofs.data_ptr(), size + 64, d_out.data_ptr())
+    _lib.default_context().synchronize()
+    assert bytes(d_proofs[:size].cpu().numpy().tobytes()) == open(GOLD, "rb").read()
+    assert int(d_proofs[size:].sum()) == 0          # nothing written past the proof
