@@ -135,7 +135,30 @@ def cpu_baseline(log_n: int, merkle_sample: int, merkle_case):
     with ThreadPoolExecutor(threads) as ex:   # ctypes releases the GIL inside the C call
         list(ex.map(lambda v: oracle.fft_fwd(v, w), xs))
     t_all = time.perf_counter() - t0
+    # whole proofs: the Python restatement of the reference's verify_mimc_proof (tests/ref_verifier.py, hashes and
+    # transform through the C oracle) on the bundled proof, and the oracle prover on the same instance
+    proofs_cpu = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import proofio
+        import ref_verifier as rv
+        from test_oracle import _oracle_hooks
+        from oracle import prover as oprover
+        gold = open(os.path.join(ROOT, "tests", "golden", "proof.bin"), "rb").read()
+        consts = rv.mimc_constants()
+        t0 = time.perf_counter()
+        out3 = rv.mimc(3, 8192, consts)
+        ok = rv.verify_mimc_proof(3, 8192, consts, out3, proofio.parse_proof(gold)[0], _oracle_hooks())
+        t_v = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        made, _ = oprover.mk_mimc_proof(3, 8192, consts)
+        t_p = time.perf_counter() - t0
+        proofs_cpu = {"batch_verify_value": 1.0 / t_v, "batch_verify_unit": "proofs/s (Python restatement + C oracle, 1 proof, %.2f s, accepted %s)" % (t_v, bool(ok)),
+                      "prove_value": 1.0 / t_p, "prove_unit": "proofs/s (Python oracle prover, 1 proof, %.2f s, equals proof.bin %s)" % (t_p, made == gold)}
+    except Exception as exc:  # the fixture or the test helpers are missing: the two transform / Merkle figures stand
+        proofs_cpu = {"batch_verify_value": None, "batch_verify_unit": "unavailable: %r" % (exc,)}
     return {
+        **proofs_cpu,
         "value": 1.0 / t_ntt, "unit": "NTT(2^%d)/s" % log_n, "cores": 1, "kind": "port",
         "sample": "1 forward 2^%d-point transform (%.2f s) and %d depth-20 branches (%.2f s), oracle/stark_oracle.c, 1 thread"
                   % (log_n, t_ntt, s, t_mk),
