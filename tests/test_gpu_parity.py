@@ -423,3 +423,23 @@ def test_merkle_build_matches_oracle(sv, log_leaves):
         pos = (idx // ld4 + 4 * (idx % ld4)).astype(np.int64)
         wit = np.stack([got[((L + pos) >> (k + 1)) ^ 1] for k in range(w)])
         assert sv.merkle_tree.verify_batch(got[L + pos], got[L + (pos ^ 1)], wit, idx, got[1]).all()
+
+
+@pytest.mark.gpu
+def test_host_copies_staged_and_direct_give_the_same_results(monkeypatch):
+    """Host-pointer entry points stage copies of 8 MiB and more through pinned buffers; STARKHIP_PINNED=0 (read when a
+    context first copies) makes them direct. Both contexts must return the same bytes, and the staged path must handle
+    sizes that are not a multiple of its 64 MiB buffers."""
+    import stark_verifier_amd as sv
+    log_n, batch = 15, 70                       # 70 MiB: two staging buffers and a partial third chunk
+    n = 1 << log_n
+    w = pow(7, (oracle.P - 1) >> log_n, oracle.P)
+    x = synth.field_elements(99, batch * n).reshape(batch, n, 8)
+    staged = sv.fft.ntt_batch(x, w, inverse=False)
+    monkeypatch.setenv("STARKHIP_PINNED", "0")
+    ctx = sv.Context(0)
+    direct = sv.fft.ntt_batch(x, w, inverse=False, ctx=ctx)
+    ctx.close()
+    assert np.array_equal(staged, direct)
+    for b in (0, 37, batch - 1):
+        assert np.array_equal(staged[b], oracle.fft_fwd(x[b], w))
