@@ -362,11 +362,16 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
         if (dev < 64) attr_set[dev] = true;
     }
     NttPassArgs b = a;
-    static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 3;  // log2 of tiles per L2 group, -1 = off
+    static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 4;  // log2 of tiles per L2 group, -1 = off
     b.tiles = tiles;
     b.polys = polys;
     b.grp_log = 0;
-    if (grp >= 0 && tiles % (8u << grp) == 0) b.grp_log = (uint32_t)grp + 1;
+    // the largest group up to 2^grp tiles that divides the tiles evenly over the 8 XCDs
+    for (int g = grp; g >= 0; g--)
+        if (tiles % (8u << g) == 0) {
+            b.grp_log = (uint32_t)g + 1;
+            break;
+        }
     if ((uint64_t)tiles * polys >= (1ull << 31)) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(ntt29_pass_kernel<LOGT>, dim3(tiles * polys), dim3(threads), lds, stream, b);
     return hipGetLastError();
