@@ -613,7 +613,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
             parallel_for((m + 63) / 64, threads, [&](size_t blk) {
                 for (size_t i = blk * 64; i < std::min(m, blk * 64 + 64); i++) {
                     const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
-                    canon[i] = (a - offsets[c0]) % 4 == 0 && fast_is_canonical(proofs + a, (size_t)(b - a));
+                    canon[i] = fast_is_canonical(proofs + a, (size_t)(b - a));
                 }
             });
         t_classify += now() - t0;
@@ -782,6 +782,21 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                     bases.push_back(offsets[c0 + i] - offsets[c0]);
                     who.push_back(i);
                 }
+            // the device reads 4-byte words: proofs that do not start on a multiple of 4 inside the chunk (a neighbour's
+            // length was odd) are copied, with the rest, into a packed buffer first
+            bool aligned = true;
+            for (uint64_t b : bases) aligned = aligned && b % 4 == 0;
+            const uint8_t* fast_chunk = chunk_base;
+            size_t fast_len = chunk_len;
+            std::vector<uint8_t> packed;
+            if (!who.empty() && !aligned) {
+                const size_t psz = fast_proof_size();
+                packed.resize(psz * who.size());
+                parallel_for(who.size(), threads, [&](size_t k) { memcpy(&packed[psz * k], chunk_base + bases[k], psz); });
+                for (size_t k = 0; k < who.size(); k++) bases[k] = psz * k;
+                fast_chunk = packed.data();
+                fast_len = packed.size();
+            }
             if (!who.empty()) {
                 std::vector<uint32_t> io(16 * who.size());
                 parallel_for((who.size() + 255) / 256, threads, [&](size_t blk) {
@@ -792,7 +807,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                     }
                 });
                 std::vector<uint8_t> st(who.size());
-                int rc = fast_verify(ctx, chunk_base, chunk_len, bases.data(), io.data(), who.size(), CP, d_mini, st.data());
+                int rc = fast_verify(ctx, fast_chunk, fast_len, bases.data(), io.data(), who.size(), CP, d_mini, st.data());
                 if (rc != STARK_OK) {
                     return rc;
                 }

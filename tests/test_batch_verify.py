@@ -274,3 +274,23 @@ def test_fast_and_general_paths_agree(proof_bytes, monkeypatch):
     assert np.array_equal(s_fast, s_gen), [(i, int(x), int(y)) for i, (x, y) in enumerate(zip(s_fast, s_gen)) if x != y]
     assert list(a_fast[-6:]) == [1, 0, 1, 0, 1, 0] and list(s_fast[-6:]) == [0, 7, 0, 7, 0, 7]
     assert set(s_fast.tolist()) >= {0, 2, 4, 7}
+
+
+def test_proofs_at_odd_offsets_take_the_fast_path_through_a_packed_copy(proof_bytes, monkeypatch, capfd):
+    """Trailing bytes of odd length (tolerated by the reference's parser) push every later proof off a 4-byte boundary;
+    such proofs are packed into an aligned buffer and still decided on the device without host parsing."""
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    v = _variants(proof_bytes)
+    blobs = []
+    for i, k in enumerate(["good", "witness_bit", "good", "trace_value_bit", "good", "root2_bit", "points_bit", "good"] * 3):
+        blobs.append(v[k] + b"\x07" * (1 + i % 5))
+    monkeypatch.setenv("STARKHIP_BATCH_TIMING", "1")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    err = capfd.readouterr().err
+    assert list(a) == [1, 0, 1, 0, 1, 0, 1, 1] * 3 and list(s) == [0, 4, 0, 4, 0, 4, 0, 0] * 3
+    assert "parse+indices 0.000 s" in err, err          # nothing went through the parsing path
+    monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
+    a2, s2 = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, a2) and np.array_equal(s, s2)
