@@ -272,6 +272,22 @@ int stark_mimc_prove_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, u
  * arithmetic: 4 = a*b, 5 = a+b, 6 = a-b, 7 = (2a-2b)*b. Exercises the device arithmetic alone. */
 int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n);
 
+/* stark_mimc_verify_batch_io with diagnostic switches, for tests that compare the verifier's paths and its scalar
+ * checks against a restatement of src/lib.rs:31-197 one check at a time. flags is a sum of:
+ *   STARK_DIAG_IGNORE_MERKLE      a Merkle mismatch (status 4) is not recorded, so the scalar checks decide alone:
+ *                                 proofs with damaged values reach statuses 5..8. Disables a soundness check: never
+ *                                 use outside tests.
+ *   STARK_DIAG_HOST_FIELD_CHECKS  the scalar checks run on host threads in the reference's own formulation
+ *                                 (Lagrange interpolation, modular division) instead of the device kernels
+ *   STARK_DIAG_GENERAL_PATH       every proof is parsed on the host (no device-side fast path) */
+#define STARK_DIAG_IGNORE_MERKLE 1u
+#define STARK_DIAG_HOST_FIELD_CHECKS 2u
+#define STARK_DIAG_GENERAL_PATH 4u
+int stark_mimc_verify_batch_diag(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                                 const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
+                                 size_t n_constants, const uint32_t* outputs, unsigned flags, uint8_t* accept,
+                                 uint8_t* status);
+
 /* Fill a device buffer with n canonical field elements drawn from SplitMix64(seed): element i
  * takes draws 4i..4i+3 as its four little-endian 64-bit words, reduced mod p. */
 int stark_fill_random_field_dev(stark_ctx* ctx, void* d_out, size_t n, uint64_t seed, void* stream);

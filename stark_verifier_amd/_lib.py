@@ -32,6 +32,7 @@ EXPORTS = [
     "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
     "stark_merkle_build", "stark_merkle_build_dev",
     "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev", "stark_mimc_batch", "stark_mimc_batch_dev",
+    "stark_mimc_verify_batch_diag",
 ]
 
 
@@ -93,6 +94,8 @@ def load() -> ctypes.CDLL:
     L.stark_mimc_verify_batch.restype = i32
     L.stark_mimc_verify_batch_io.argtypes = [vp, vp, vp, sz, vp, u64, vp, sz, vp, vp, vp]
     L.stark_mimc_verify_batch_io.restype = i32
+    L.stark_mimc_verify_batch_diag.argtypes = [vp, vp, vp, sz, vp, u64, vp, sz, vp, ctypes.c_uint, vp, vp]
+    L.stark_mimc_verify_batch_diag.restype = i32
     L.stark_mimc_verify_batch_dev.argtypes = [vp, vp, u64, sz, vp, u64, vp, sz, vp, vp, vp]
     L.stark_mimc_verify_batch_dev.restype = i32
     L.stark_pseudorandom_indices.argtypes = [vp, vp, sz, u32, u32, u32, vp]

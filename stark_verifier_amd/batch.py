@@ -58,6 +58,31 @@ def verify_mimc_batch_io(proofs: Sequence[bytes], inputs: Sequence[int], num_ste
     return accept, status
 
 
+DIAG_IGNORE_MERKLE, DIAG_HOST_FIELD_CHECKS, DIAG_GENERAL_PATH = 1, 2, 4
+
+
+def verify_mimc_batch_diag(proofs: Sequence[bytes], inputs: Sequence[int], num_steps: int, round_constants: Sequence[int],
+                           outputs: Sequence[int], flags: int, ctx: _lib.Context | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Test support: verify_mimc_batch_io with the library's diagnostic switches (a sum of DIAG_*).
+    DIAG_IGNORE_MERKLE lets the scalar checks decide even when a branch mismatched; never use it to verify."""
+    ctx = ctx or _lib.default_context()
+    n = len(proofs)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(p) for p in proofs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(proofs), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    rc = np.ascontiguousarray(np.concatenate([_limbs(c % MODULUS) for c in round_constants]) if len(round_constants)
+                              else np.zeros(0, dtype=np.uint32))
+    i = np.ascontiguousarray(np.concatenate([_limbs(int(x) % MODULUS) for x in inputs])) if n else np.zeros(8, dtype=np.uint32)
+    o = np.ascontiguousarray(np.concatenate([_limbs(int(x) % MODULUS) for x in outputs])) if n else np.zeros(8, dtype=np.uint32)
+    accept = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.uint8)
+    ctx.check(ctx.lib.stark_mimc_verify_batch_diag(ctx.handle, blob.ctypes.data if n else None, offsets.ctypes.data, n,
+                                                   i.ctypes.data, num_steps, rc.ctypes.data if rc.size else None,
+                                                   len(round_constants), o.ctypes.data, flags,
+                                                   accept.ctypes.data if n else None, status.ctypes.data if n else None))
+    return accept, status
+
+
 def verify_mimc_batch_dev(d_proofs: int, proof_stride: int, n: int, d_inputs: int, num_steps: int,
                           round_constants: Sequence[int], d_outputs: int,
                           ctx: _lib.Context | None = None) -> Tuple[np.ndarray, np.ndarray]:

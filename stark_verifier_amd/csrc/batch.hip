@@ -81,6 +81,19 @@ static U256 from_be_n(const uint8_t* b, size_t n) {
     return r;
 }
 static bool is_zero(const U256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+// BigInt::from_bytes_be(n bytes) == v as integers, v canonical (no reduction of the bytes)
+static bool raw_be_equals(const uint8_t* b, size_t n, const U256& v) {
+    if (n < 32) return false;
+    for (size_t i = 0; i + 32 < n; i++)
+        if (b[i]) return false;
+    b += n - 32;
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) w = (w << 8) | b[8 * (3 - i) + k];
+        if (w != v.w[i]) return false;
+    }
+    return true;
+}
 
 // ---- wire format (src/deserializer.rs) ----
 struct BranchRef {
@@ -158,23 +171,26 @@ static bool parse_proof(const uint8_t* p, size_t len, Proof& out) {  // deserial
     return parse_multiproof(r, out.merkle) && parse_multiproof(r, out.lincomb);  // trailing bytes are tolerated
 }
 
-// src/utils.rs:53-94
-static std::vector<uint32_t> pseudorandom_indices(const uint8_t seed[32], size_t count, uint32_t modulus, uint32_t exclude) {
+// src/utils.rs:53-94. False when the reduced modulus is zero: the reference's `x % real_modulus` (:85) panics there.
+static bool pseudorandom_indices(const uint8_t seed[32], size_t count, uint32_t modulus, uint32_t exclude,
+                                 std::vector<uint32_t>& out) {
     const uint32_t real_modulus = exclude ? (uint32_t)(modulus * (exclude - 1) / exclude) : modulus;
+    out.clear();
+    if (real_modulus == 0) return false;
     std::vector<uint8_t> hashes(seed, seed + 32);
     while (hashes.size() < 4 * count) {
         uint8_t d[32];
         hostb2s::hash(hashes.data() + hashes.size() - 32, 32, d);
         hashes.insert(hashes.end(), d, d + 32);
     }
-    std::vector<uint32_t> out(count);
+    out.resize(count);
     for (size_t j = 0; j < count; j++) {
         const uint8_t* b = hashes.data() + 4 * j;
         uint32_t x = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
         out[j] = x % real_modulus;
         if (exclude) out[j] = 1 + out[j] + out[j] / (exclude - 1);
     }
-    return out;
+    return true;
 }
 
 enum Status : uint8_t {
@@ -226,23 +242,47 @@ struct ProofWork {
     bool plain_values = true;  // every value the scalar checks read as one number is 32 bytes (device lanes copy 32)
 };
 
-// Index derivation and the shape checks the reference makes before hashing.
+// The panics MultiProof::verify / ProofBranch::verify raise on a query before any hashing: branch count
+// (assert at merkle_tree.rs:28), no witnesses (division by zero at :113), value shorter than 32 bytes (slice at :133);
+// more than 30 witnesses overflow the u32 tree size at :120.
+static bool query_shape_ok(const Query& q) {
+    if (q.branches->size() != q.indices.size()) return false;
+    for (const BranchRef& b : *q.branches)
+        if (b.w == 0 || b.w > 30 || b.vs < 32) return false;
+    return true;
+}
+
+// Index derivation and the shape checks the reference makes before hashing, in the reference's order: layer by
+// layer (lib.rs:53-92), each layer's two multiproofs checked before the next layer's indices are drawn, so a proof
+// with more layers than the domain has factors of four stops where the reference panics and never reaches a zero
+// modulus.
 static void prepare(ProofWork& pw, const Params& P) {
     const Proof& pr = pw.proof;
     uint64_t rou_deg = P.precision;  // order of G2
     const uint8_t* root = pr.l_root;
     for (const Layer& l : pr.layers) {
-        std::vector<uint32_t> ys = pseudorandom_indices(l.root2, 40, (uint32_t)(rou_deg / 4), 8);
+        std::vector<uint32_t> ys;
+        if (!pseudorandom_indices(l.root2, 40, (uint32_t)(rou_deg / 4), 8, ys)) {  // `% 0` panic at utils.rs:85
+            pw.status = ST_SHAPE;
+            return;
+        }
         std::vector<uint32_t> pp;
         for (uint32_t y : ys)
             for (uint32_t i = 0; i < 4; i++) pp.push_back(y + (uint32_t)(rou_deg / 4) * i);
         pw.queries.push_back(Query{&l.col, ys, l.root2});
         pw.queries.push_back(Query{&l.poly, pp, root});
+        if (!query_shape_ok(pw.queries[pw.queries.size() - 2]) || !query_shape_ok(pw.queries.back())) {
+            pw.status = ST_SHAPE;
+            return;
+        }
         pw.ys.push_back(std::move(ys));
         rou_deg /= 4;
         root = l.root2;
     }
-    pw.positions = pseudorandom_indices(pr.l_root, 80, (uint32_t)P.precision, 8);
+    if (!pseudorandom_indices(pr.l_root, 80, (uint32_t)P.precision, 8, pw.positions)) {
+        pw.status = ST_SHAPE;
+        return;
+    }
     std::vector<uint32_t> aug;
     for (uint32_t p : pw.positions) {
         aug.push_back(p);
@@ -250,16 +290,9 @@ static void prepare(ProofWork& pw, const Params& P) {
     }
     pw.queries.push_back(Query{&pr.merkle, aug, pr.merkle_root});
     pw.queries.push_back(Query{&pr.lincomb, pw.positions, pr.l_root});
-    for (const Query& q : pw.queries) {
-        if (q.branches->size() != q.indices.size()) {  // assert at merkle_tree.rs:28
-            pw.status = ST_SHAPE;
-            return;
-        }
-        for (const BranchRef& b : *q.branches)
-            if (b.w == 0 || b.w > 30 || b.vs < 32) {  // division by zero at :113, slice at :133, 2^w overflow
-                pw.status = ST_SHAPE;
-                return;
-            }
+    if (!query_shape_ok(pw.queries[pw.queries.size() - 2]) || !query_shape_ok(pw.queries.back())) {
+        pw.status = ST_SHAPE;
+        return;
     }
     for (const Layer& l : pr.layers) {
         for (const BranchRef& b : l.col) pw.plain_values &= b.vs == 32;
@@ -315,7 +348,9 @@ static uint8_t field_checks(const ProofWork& pw, const Params& P, size_t gi) {
             }
             interp_4(xs, rows, poly);
             const U256 got = fe_add(fe_add(poly[0], fe_mul(poly[1], special_x)), fe_add(fe_mul(poly[2], sx2), fe_mul(poly[3], sx3)));
-            if (!hostfe::eq(got, from_be_n(l.col[i].value, l.col[i].vs))) return ST_LOW_DEGREE;
+            // :85 compares the reduced evaluation with BigInt::from_bytes_be(column value), which is not reduced: a
+            // column value at or above p (or with non-zero bytes in front of its last 32) can never be equal
+            if (!raw_be_equals(l.col[i].value, l.col[i].vs, got)) return ST_LOW_DEGREE;
         }
         rou = hostfe::pow_u64(rou, 4);
         rou_deg /= 4;
@@ -485,13 +520,13 @@ struct Setup {
     Params P;
     CheckParams CP;
     uint32_t* d_mini = nullptr;  // constants_mini_polynomial on the device (when the scalar checks run there)
-    bool field_on_host = false, skip_merkle = false, force_flatten = false;
+    bool field_on_host = false, skip_merkle = false, force_flatten = false, force_general = false;
     ~Setup() { (void)hipFree(d_mini); }
 };
 
 // early: ST_ACCEPT when proofs have to be looked at, else the status every proof gets (lib.rs:101-111, :120-123)
 static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_constants, size_t n_constants, Setup& S,
-                      uint8_t& early) {
+                      uint8_t& early, unsigned flags = 0) {
     Params& P = S.P;
     CheckParams& CP = S.CP;
     early = ST_ACCEPT;
@@ -533,14 +568,16 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
         if (rc != STARK_OK) return rc;
         for (size_t i = 0; i < n_constants; i++) P.mini_poly.push_back(hostfe::from_limbs(out.data() + 8 * i));
     }
-    // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host
+    // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host (equivalent paths)
     const char* fenv = getenv("STARKHIP_BATCH_FIELD");
-    S.field_on_host = fenv && strcmp(fenv, "host") == 0;
-    // diagnostic: let the scalar checks decide even when a branch mismatched (compares the host and device
-    // versions of those checks on corrupted values); never set in production
-    S.skip_merkle = getenv("STARKHIP_BATCH_IGNORE_MERKLE") != nullptr;
+    S.field_on_host = (fenv && strcmp(fenv, "host") == 0) || (flags & STARK_DIAG_HOST_FIELD_CHECKS);
+    // test only, reachable through stark_mimc_verify_batch_diag alone: the scalar checks decide even when a branch
+    // mismatched, so damaged values exercise every check
+    S.skip_merkle = (flags & STARK_DIAG_IGNORE_MERKLE) != 0;
     const char* menv = getenv("STARKHIP_BATCH_MERKLE");
     S.force_flatten = menv && strcmp(menv, "flatten") == 0;
+    const char* penv = getenv("STARKHIP_BATCH_PATH");
+    S.force_general = (penv && strcmp(penv, "general") == 0) || (flags & STARK_DIAG_GENERAL_PATH);
     hostfe::to_limbs(P.g2, CP.g2);
     hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
     hostfe::to_limbs(P.last_step, CP.last_step);
@@ -560,7 +597,7 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
 
 static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs, const uint32_t* inp,
                        const uint32_t* output, size_t io_stride, uint64_t num_steps, const uint32_t* round_constants,
-                       size_t n_constants, uint8_t* accept, uint8_t* status) {
+                       size_t n_constants, uint8_t* accept, uint8_t* status, unsigned flags = 0) {
     if (!ctx) return STARK_ERR_INVALID;
     if (ctx_make_current(ctx) != hipSuccess) return STARK_ERR_HIP;
     if (n_proofs && (!proofs || !offsets || !accept)) return STARK_ERR_INVALID;
@@ -577,7 +614,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     Setup S;
     uint8_t early;
     {
-        int rc = make_setup(ctx, num_steps, round_constants, n_constants, S, early);
+        int rc = make_setup(ctx, num_steps, round_constants, n_constants, S, early, flags);
         if (rc != STARK_OK) return rc;
     }
     if (early != ST_ACCEPT) return set_all(early);
@@ -597,9 +634,8 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     // STARKHIP_BATCH_TIMING=1 prints per-stage wall time to stderr
     const bool timing = getenv("STARKHIP_BATCH_TIMING") != nullptr;
     double t_parse = 0, t_bucket = 0, t_flatten = 0, t_merkle = 0, t_field = 0, t_classify = 0, t_fast = 0;
-    // STARKHIP_BATCH_PATH=general: every proof takes the parsing path (the diagnostic switches above imply it)
-    const char* penv = getenv("STARKHIP_BATCH_PATH");
-    const bool use_fast = !(penv && strcmp(penv, "general") == 0) && !field_on_host && !force_flatten && !skip_merkle;
+    // STARKHIP_BATCH_PATH=general: every proof takes the parsing path (the other switches imply it)
+    const bool use_fast = !S.force_general && !field_on_host && !force_flatten && !skip_merkle;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t c0 = 0; c0 < n_proofs;) {
         size_t c1 = c0 + 1;
@@ -857,8 +893,7 @@ extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs,
         return STARK_OK;
     }
     hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
-    const char* penv = getenv("STARKHIP_BATCH_PATH");
-    const bool use_fast = !(penv && strcmp(penv, "general") == 0) && !S.field_on_host && !S.force_flatten && !S.skip_merkle;
+    const bool use_fast = !S.force_general && !S.field_on_host && !S.force_flatten;
     std::vector<uint8_t> canon(n_proofs, 0), stv(n_proofs, 0);
     if (use_fast && (rc = fast_classify_resident(ctx, (const uint8_t*)d_proofs, proof_stride, n_proofs, canon.data())) != STARK_OK)
         return rc;
@@ -928,4 +963,14 @@ extern "C" int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs,
                                           const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
                                           size_t n_constants, const uint32_t* outputs, uint8_t* accept, uint8_t* status) try {
     return verify_impl(ctx, proofs, offsets, n_proofs, inputs, outputs, 8, num_steps, round_constants, n_constants, accept, status);
+} STARK_CATCH
+
+// Test support: stark_mimc_verify_batch_io with diagnostic switches (STARK_DIAG_*). The only way to make the
+// verifier overlook a Merkle mismatch; nothing in the library calls it.
+extern "C" int stark_mimc_verify_batch_diag(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
+                                            const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
+                                            size_t n_constants, const uint32_t* outputs, unsigned flags, uint8_t* accept,
+                                            uint8_t* status) try {
+    return verify_impl(ctx, proofs, offsets, n_proofs, inputs, outputs, 8, num_steps, round_constants, n_constants, accept,
+                       status, flags);
 } STARK_CATCH

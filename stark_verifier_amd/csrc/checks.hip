@@ -48,6 +48,26 @@ __device__ __forceinline__ F29 load_be(const uint8_t* p) {
     return norm(f29_from_fe(x));
 }
 
+// Do these 32 big-endian bytes spell a number below p? (BigInt::from_bytes_be does not reduce.)
+__device__ __forceinline__ bool be_is_canonical(const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    Fe x;
+    x.l[7] = __builtin_bswap32(a.x);
+    x.l[6] = __builtin_bswap32(a.y);
+    x.l[5] = __builtin_bswap32(a.z);
+    x.l[4] = __builtin_bswap32(a.w);
+    x.l[3] = __builtin_bswap32(b.x);
+    x.l[2] = __builtin_bswap32(b.y);
+    x.l[1] = __builtin_bswap32(b.z);
+    x.l[0] = __builtin_bswap32(b.w);
+    const Fe c = f29_to_fe(f29_from_fe(x));
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= c.l[i] ^ x.l[i];
+    return d == 0;
+}
+
 __device__ __forceinline__ F29 load_limbs(const uint32_t* l) {
     Fe x;
 #pragma unroll
@@ -103,7 +123,9 @@ __global__ void __launch_bounds__(256) fri_check_kernel(const FriLane* __restric
     acc = add_t(mul_t(acc, t), k1);
     acc = add_t(mul_t(acc, t), k0);
     const F29 four_col = add_t(add_t(col, col), add_t(col, col));
-    status[i] = is_zero_t(sub_t(acc, four_col)) ? 0 : 5;
+    // src/lib.rs:85 compares the reduced evaluation with the column value as BigInt::from_bytes_be gives it,
+    // unreduced: a column value encoded at or above p never compares equal there
+    status[i] = (is_zero_t(sub_t(acc, four_col)) && be_is_canonical(L.col)) ? 0 : 5;
 }
 
 __global__ void __launch_bounds__(256) constraint_check_kernel(const ConstraintLane* __restrict__ lanes, size_t n,

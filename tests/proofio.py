@@ -92,3 +92,35 @@ def parse_proof(b: bytes):
     mb, off = parse_multiproof(b, off)
     lb, off = parse_multiproof(b, off)
     return StarkProof(merkle_root, l_merkle_root, layers, points, mb, lb), off
+
+
+def value_offsets(b: bytes):
+    """Byte offset of every branch's `value` field: {("col" | "poly", layer, i) | ("merkle", i) | ("lincomb", i): offset}."""
+    out = {}
+
+    def walk(off, key):
+        n = _u32(b, off)
+        off += 4
+        for i in range(n):
+            vs = _u32(b, off)
+            out[key + (i,)] = off + 4
+            off += 4 + 2 * vs
+            off += 4 + _u32(b, off)
+        return off
+
+    off, layer = 64, 0
+    while True:
+        t = _u32(b, off)
+        off += 4
+        if t == 1:
+            off = walk(off + 32, ("col", layer))
+            off = walk(off, ("poly", layer))
+            layer += 1
+        elif t == 2:
+            off += 4 + _u32(b, off)
+            break
+        else:
+            raise ValueError("invalid proof element type")
+    off = walk(off, ("merkle",))
+    walk(off, ("lincomb",))
+    return out

@@ -74,3 +74,44 @@ def test_cfg3_single_2_24_transform_and_sharded_path():
     xs = ntt_sharded(ys, log_n, w, True, ops=ops)
     torch.cuda.synchronize()
     assert torch.equal(xs, x)
+
+
+def test_headline_shape_64_polys_of_2_20_against_the_oracle_in_full():
+    """The benchmark's own shape (64 polynomials of 2^20 points in one call, the 2 GiB chunk of the multi-pass path):
+    six polynomials spread over the batch are compared element by element with the oracle's restatement of
+    fft.rs:37-86, forward and inverse (fft_inv semantics, src/fft.rs:64-86), out of place and in place."""
+    import stark_verifier_amd as sv
+    from stark_verifier_amd import fft
+    ctx = sv.default_context()
+    log_n, B = 20, 64
+    n = 1 << log_n
+    w = pow(7, (P - 1) >> log_n, P)
+    assert w == 0xd3cd75fbef8d5e5ff367cbc0866ba9b493e153ed47f2c01c2b996aa041d2363b
+    x = _fill(ctx, B * n, SEED + 20)
+    y = torch.empty_like(x)
+    fft.ntt_batch_dev(x.data_ptr(), y.data_ptr(), log_n, B, w, False, ctx)
+    ctx.synchronize()
+    picks = (0, 1, 17, 31, 32, 63)
+    host = lambda t, b: t[b * n:(b + 1) * n].cpu().numpy().view(np.uint32)
+    for b in picks:
+        assert np.array_equal(host(y, b), oracle.fft_fwd(host(x, b), w)), ("forward", b)
+    # inverse of fresh data (not of the forward output, so an error the two directions share cannot cancel)
+    z = torch.empty_like(x)
+    fft.ntt_batch_dev(x.data_ptr(), z.data_ptr(), log_n, B, w, True, ctx)
+    ctx.synchronize()
+    for b in picks:
+        assert np.array_equal(host(z, b), oracle.fft_inv(host(x, b), w)), ("inverse", b)
+    # in place: same bytes as out of place, both directions
+    t = x.clone()
+    torch.cuda.synchronize()              # torch copies on its own stream, the library launches on the context's
+    fft.ntt_batch_dev(t.data_ptr(), t.data_ptr(), log_n, B, w, False, ctx)
+    ctx.synchronize()
+    assert torch.equal(t, y)
+    fft.ntt_batch_dev(t.data_ptr(), t.data_ptr(), log_n, B, w, True, ctx)
+    ctx.synchronize()
+    assert torch.equal(t, x)
+    t.copy_(x)
+    torch.cuda.synchronize()
+    fft.ntt_batch_dev(t.data_ptr(), t.data_ptr(), log_n, B, w, True, ctx)
+    ctx.synchronize()
+    assert torch.equal(t, z)
