@@ -634,6 +634,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     // STARKHIP_BATCH_TIMING=1 prints per-stage wall time to stderr
     const bool timing = getenv("STARKHIP_BATCH_TIMING") != nullptr;
     double t_parse = 0, t_bucket = 0, t_flatten = 0, t_merkle = 0, t_field = 0, t_classify = 0, t_fast = 0;
+    size_t n_parsed = 0;  // proofs that took the parsing path
     // STARKHIP_BATCH_PATH=general: every proof takes the parsing path (the other switches imply it)
     const bool use_fast = !S.force_general && !field_on_host && !force_flatten && !skip_merkle;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -668,6 +669,7 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
             prepare(pw, P);
         });
         t_parse += now() - t0;
+        for (size_t i = 0; i < m; i++) n_parsed += !canon[i];
         t0 = now();
         // bucket every branch of the chunk by shape; roots are deduplicated per proof
         std::map<std::pair<uint32_t, uint32_t>, Bucket> buckets;
@@ -858,8 +860,8 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         c0 = c1;
     }
     if (timing)
-        fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: structure check %.3f s, fast path (upload + kernels) %.3f s; general path: parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
-                n_proofs, t_classify, t_fast, t_parse, t_bucket, t_flatten, t_merkle, t_field);
+        fprintf(stderr, "stark_mimc_verify_batch: %zu proofs: structure check %.3f s, fast path (upload + kernels) %.3f s; general path (%zu proofs parsed on the host): parse+indices %.3f s, bucketing %.3f s, flatten %.3f s, merkle (copies+kernel) %.3f s, field checks %.3f s\n",
+                n_proofs, t_classify, t_fast, n_parsed, t_parse, t_bucket, t_flatten, t_merkle, t_field);
     return STARK_OK;
 }
 
