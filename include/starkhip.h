@@ -102,6 +102,23 @@ int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned 
                         const uint32_t root_of_unity[8], int inverse, void* stream);
 
 /*
+ * stark_ntt_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments and results as
+ * stark_ntt_batch_dev, but it calls no hipMalloc / hipFree: the multi-pass intermediate goes to a fixed
+ * STARK_STATIC_SCRATCH_BYTES array that is part of the library's device image (one copy per GPU, held until the
+ * process ends), and the twiddle tables must already be in the context: call stark_ntt_batch_dev once with the same
+ * (log_n, root_of_unity, inverse) beforehand (batch 0 is enough), otherwise STARK_ERR_INVALID. Transforms above
+ * STARK_STATIC_MAX_LOG_N points do not fit the array: STARK_ERR_UNSUPPORTED. All calls on one GPU, from any
+ * context, share that GPU's array: calls that overlap in time on one GPU race (queue them on one stream or order
+ * them with events). Nothing in the array has to be cleared between calls: every word a pass reads was written by
+ * the pass before it in the same call.
+ */
+#define STARK_STATIC_SCRATCH_BYTES ((size_t)48 << 20) /* 2^20 points x 48 bytes */
+#define STARK_STATIC_MAX_LOG_N 20
+int stark_ntt_batch_dev_static(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
+                               const uint32_t root_of_unity[8], int inverse, void* stream);
+
+/*
  * Local steps of one transform sharded over several GPUs. A transform of n = n1 * n2 points
  * (input index j = j1 + n1*j2, output index k = k1*n2 + k2) is
  *   (A) for every j1: an n2-point transform over j2        -> stark_ntt_batch_dev, root^n1

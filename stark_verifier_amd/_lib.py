@@ -32,7 +32,7 @@ EXPORTS = [
     "stark_mimc_verify_batch", "stark_pseudorandom_indices", "stark_pseudorandom_indices_dev",
     "stark_merkle_build", "stark_merkle_build_dev",
     "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev", "stark_mimc_batch", "stark_mimc_batch_dev",
-    "stark_mimc_verify_batch_diag",
+    "stark_mimc_verify_batch_diag", "stark_ntt_batch_dev_static",
 ]
 
 
@@ -78,6 +78,8 @@ def load() -> ctypes.CDLL:
     L.stark_ntt_batch.restype = i32
     L.stark_ntt_batch_dev.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
     L.stark_ntt_batch_dev.restype = i32
+    L.stark_ntt_batch_dev_static.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
+    L.stark_ntt_batch_dev_static.restype = i32
     L.stark_merkle_verify_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, u32, vp, sz, vp, vp]
     L.stark_merkle_verify_batch.restype = i32
     L.stark_merkle_verify_batch_dev.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, vp, sz, vp, vp, vp]

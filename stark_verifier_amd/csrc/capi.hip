@@ -18,6 +18,13 @@
 using namespace starkhip;
 using hostfe::U256;
 
+// Scratch of the allocation-free transform entry point (stark_ntt_batch_dev_static): the multi-pass intermediate
+// lives here instead of in a buffer the context allocates. Every device the library runs on holds its own copy from
+// load to process exit. In host code the array's name is only a handle: stark_ctx_create asks the runtime for the
+// device address once per context (hipGetSymbolAddress, that context's device current) and only that pointer is ever
+// handed to kernels.
+static __device__ __align__(256) unsigned char g_static_scratch[STARK_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 struct PassPlan {
@@ -51,6 +58,7 @@ struct stark_ctx {
     std::vector<std::unique_ptr<NttPlan>> shard_tables;  // two-level power tables of stark_twiddle_mul_dev (passes unused)
     void* scratch = nullptr;  // multi-pass intermediate
     size_t scratch_bytes = 0;
+    void* static_scratch = nullptr;  // device address of g_static_scratch on this context's device
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
     size_t chunk_bytes = (size_t)2048 << 20;  // input bytes transformed per group of pass launches (scratch = 1.5x)
@@ -538,7 +546,9 @@ bool has_order(const U256& root, unsigned log_n) {
     return hostfe::eq(x, one);
 }
 
-int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_out, size_t batch, hipStream_t stream) {
+// fixed != nullptr: the multi-pass intermediate goes to that buffer of fixed_bytes and nothing is allocated
+int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_out, size_t batch, hipStream_t stream,
+             void* fixed = nullptr, size_t fixed_bytes = 0) {
     const uint64_t n = (uint64_t)1 << plan->log_n;
     if (batch == 0) return STARK_OK;
     if (plan->tiny) {
@@ -569,9 +579,18 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     if (chunk > 65535) chunk = 65535;
-    int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, chunk * n * mid_bytes);
-    if (rc != STARK_OK) return rc;
-    uint32_t* tmp = (uint32_t*)ctx->scratch;
+    uint32_t* tmp;
+    if (fixed) {
+        if (n * mid_bytes > fixed_bytes)
+            return fail(ctx, STARK_ERR_UNSUPPORTED, "2^%u points need %zu bytes of intermediate, the static scratch has %zu",
+                        plan->log_n, (size_t)(n * mid_bytes), fixed_bytes);
+        if (chunk > fixed_bytes / (n * mid_bytes)) chunk = fixed_bytes / (n * mid_bytes);
+        tmp = (uint32_t*)fixed;
+    } else {
+        int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, chunk * n * mid_bytes);
+        if (rc != STARK_OK) return rc;
+        tmp = (uint32_t*)ctx->scratch;
+    }
     for (size_t done = 0; done < batch; done += chunk) {
         size_t cnt = batch - done < chunk ? batch - done : chunk;
         for (size_t k = 0; k < plan->passes.size(); k++) {
@@ -623,6 +642,12 @@ int stark_ctx_create(int device, stark_ctx** out) try {
     stark_ctx* ctx = new stark_ctx;
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return STARK_ERR_HIP;
+    }
+    // device address of the static scratch on this device (each device holds its own copy at its own address)
+    if (hipGetSymbolAddress(&ctx->static_scratch, HIP_SYMBOL(g_static_scratch)) != hipSuccess || !ctx->static_scratch) {
+        (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return STARK_ERR_HIP;
     }
@@ -713,6 +738,26 @@ int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned 
     if (!root_of_unity || (batch && (!d_in || !d_out))) return fail(ctx, STARK_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ntt_common(ctx, d_in, d_out, log_n, batch, root_of_unity, inverse, stream ? (hipStream_t)stream : ctx->stream);
+} STARK_CATCH
+
+int stark_ntt_batch_dev_static(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
+                               const uint32_t root_of_unity[8], int inverse, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || (batch && (!d_in || !d_out))) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_n > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 30", log_n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const U256 r = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(r, log_n)) return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    // tables are never built here: only a plan an earlier stark_ntt_batch_dev call left in the context is used
+    NttPlan* plan = nullptr;
+    for (auto& p : ctx->plans)
+        if (p->log_n == log_n && p->inverse == (inverse != 0) && hostfe::eq(p->root, r)) plan = p.get();
+    if (!plan)
+        return fail(ctx, STARK_ERR_INVALID,
+                    "no twiddle tables for this (log_n, root, direction) yet: call stark_ntt_batch_dev once (batch 0 is enough)");
+    plan->last_use = ++ctx->use_counter;
+    return run_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_out, batch, stream ? (hipStream_t)stream : ctx->stream,
+                    ctx->static_scratch, STARK_STATIC_SCRATCH_BYTES);
 } STARK_CATCH
 
 int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch, const uint32_t root_of_unity[8],
