@@ -41,7 +41,6 @@ struct NttPlan {
     std::vector<PassPlan> passes;
     std::vector<void*> tables;
     bool tiny = false;  // n <= 2
-    bool limb29 = true;  // passes run on the 29-bit-limb kernels (intermediates are 48 bytes/element)
     uint32_t scale[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     int has_scale = 0;
     size_t table_bytes = 0;   // device memory held by `tables`
@@ -237,11 +236,11 @@ std::vector<int> choose_split(unsigned log_n) {
 }
 
 // Tiles per workgroup (log2): as many as fit the thread and LDS budget and the extent.
-int choose_log_c(int log_t, unsigned log_extent, int target_threads, bool limb29) {
+int choose_log_c(int log_t, unsigned log_extent, int target_threads) {
     int log_q = log_t - 2;
     int log_c = 0;
     int lim = env_int("STARKHIP_LDS_LIMIT", 80 * 1024);
-    auto lds = [&](int lc) { return (int)(limb29 ? ntt29_pass_lds_bytes(log_t, lc) : ntt_pass_lds_bytes(log_t, lc)); };
+    auto lds = [&](int lc) { return (int)ntt29_pass_lds_bytes(log_t, lc); };
     while (log_c + 1 <= (int)log_extent && (1 << (log_q + log_c + 1)) <= target_threads && lds(log_c + 1) <= lim)
         log_c++;
     return log_c;
@@ -332,15 +331,14 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
         return STARK_OK;
     }
 
-    const bool l29 = env_int("STARKHIP_ARITH", 29) != 32;
-    plan->limb29 = l29;
+    const bool l29 = true;  // tile twiddle tables are stored unpacked (12 dwords per entry)
     std::vector<int> split = choose_split(log_n);
     const int target_threads = env_int("STARKHIP_THREADS", 512);
     const int forced_log_c = env_int("STARKHIP_LOGC", -1);
     auto pick_c = [&](int log_t, unsigned log_extent) {
-        int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads, l29);
+        int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads);
         if (forced_log_c >= 0 && forced_log_c <= (int)log_extent && (1 << (log_t - 2 + forced_log_c)) <= 1024 &&
-            (l29 ? ntt29_pass_lds_bytes(log_t, forced_log_c) : ntt_pass_lds_bytes(log_t, forced_log_c)) <= 160 * 1024)
+            ntt29_pass_lds_bytes(log_t, forced_log_c) <= 160 * 1024)
             lc = forced_log_c;
         return lc;
     };
@@ -566,15 +564,12 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.in = d_in + 8 * n * done;
             a.out = d_out + 8 * n * done;
             a.c_limit = cnt;
-            if (plan->limb29)
-                HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
-            else
-                HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
+            HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
         }
         return STARK_OK;
     }
     // multi-pass: first pass into scratch, middle pass in place there, last pass to d_out
-    const size_t mid_bytes = plan->limb29 ? 48 : 32;  // bytes per element of the intermediate
+    const size_t mid_bytes = 48;  // bytes per element of the intermediate (nine unpacked limbs, padded)
     size_t chunk = ctx->chunk_bytes / (n * 32);
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
@@ -598,13 +593,9 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             NttPassArgs a = p.args;
             a.in = k == 0 ? d_in + 8 * n * done : tmp;
             a.out = k + 1 == plan->passes.size() ? d_out + 8 * n * done : tmp;
-            if (plan->limb29) {
-                a.in_raw = k > 0;
-                a.out_raw = k + 1 < plan->passes.size();
-                HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
-            } else {
-                HIP_TRY(ctx, launch_ntt_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
-            }
+            a.in_raw = k > 0;
+            a.out_raw = k + 1 < plan->passes.size();
+            HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
         }
     }
     return STARK_OK;

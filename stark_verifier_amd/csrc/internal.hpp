@@ -34,7 +34,7 @@ hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, 
                                 const uint8_t* roots, const uint32_t* root_ids, size_t n, uint8_t* accept,
                                 uint8_t* digests, hipStream_t stream);
 
-// ---- ntt.hip ----
+// ---- ntt29.hip ----
 // One pass of the multi-pass transform: every workgroup transforms 2^log_c tiles of 2^log_t
 // elements. All offsets are in field elements (32 bytes each).
 //   tile index tau = blockIdx.x, hi = tau >> dsh, lo = tau & dmask, c in [0, 2^log_c)
@@ -65,12 +65,11 @@ struct NttPassArgs {
     uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)
 };
 
-size_t ntt_pass_lds_bytes(int log_t, int log_c);
-hipError_t launch_ntt_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
-// the same pass on 29-bit-limb arithmetic (ntt29.hip); W entries are 12 unpacked dwords
+// W entries are 12 unpacked dwords
 size_t ntt29_pass_lds_bytes(int log_t, int log_c);
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
 hipError_t launch_unpack_table(const uint32_t* in, uint32_t* out, size_t count, hipStream_t stream);
+// ---- tables.hip ----
 // n = 1 or 2 (no radix-4 round exists): out = transform(in), one lane per polynomial
 hipError_t launch_ntt_tiny(const uint32_t* in, uint32_t* out, int log_n, size_t batch, const uint32_t scale[8],
                            int has_scale, hipStream_t stream);

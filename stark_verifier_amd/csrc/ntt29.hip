@@ -1,8 +1,21 @@
-// Tile-transform pass kernel on 29-bit-limb ("carry-free") arithmetic — the production path.
+// Number-theoretic transform over p = 2^256 - 351*2^32 + 1 for gfx950: the tile-transform pass kernel.
 //
-// Same transform and the same pass / tile geometry as described in ntt.hip (what the
-// reference's _fft computes, reference src/fft.rs:37-61, natural order in and out, canonical
-// outputs); what differs is the representation inside the kernel:
+// Computes what the reference's _fft does (reference src/fft.rs:37-61; base case simple_ft :18-35): natural-order
+// in, natural-order out, out[i] = sum_j v[j] * w^(i*j) mod p, every output the canonical residue. The reference
+// recurses on heap BigInts; here a transform of 2^log_n points is one to three passes, each pass a grid of
+// workgroups that transform tiles of up to 4096 points held in LDS:
+//
+//   * inside a tile: Stockham autosort, radix-4 per lane (two butterfly levels per LDS round trip, preceded by one
+//     radix-2 level when log2(tile) is odd). A lane keeps its four elements in registers.
+//   * across tiles (domains larger than LDS): the four-step split n = n1*m. Pass 1 transforms columns (stride m) and
+//     multiplies output (k1, j) by w^(k1*j) from a table; the remaining passes transform the rows and store
+//     transposed, out[k1 + n1*k]. Workgroups take several adjacent columns / rows so every global access is a run of
+//     contiguous elements.
+//
+// The inverse transform (reference fft_inv, src/fft.rs:64-86) runs the same kernel with the inverse root; its n^-1
+// factor is folded into the inter-pass twiddle table (or, for single-pass sizes, applied at the final store).
+//
+// Representation inside the kernel (29-bit limbs, "carry-free", field29.cuh):
 //   * on load an element (8 x 32-bit limbs in HBM) is unpacked to nine 29-bit limbs; in LDS an
 //     element is nine adjacent dwords;
 //   * butterfly additions and subtractions are limb-wise v_add_u32 / v_sub_u32 with no carry
