@@ -231,7 +231,10 @@ int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs, const uint
  * proof_stride bytes at d_proofs + i * proof_stride (proof_stride a multiple of 4; bytes after a complete proof are
  * ignored, as the reference's parser ignores them); d_inputs and d_outputs are n_proofs x 8 limbs in device memory
  * (16-byte aligned; d_proofs 4-byte aligned); round_constants, accept and status are host pointers. Returns after the
- * verdicts have been written. */
+ * verdicts have been written. The device buffers are read on the context's own stream (stark_ctx_stream), which does
+ * not wait for any other stream: work that produces them on another stream (a caller's stream passed to
+ * stark_mimc_prove_batch_dev, torch's current stream) must have completed, or that stream must have been
+ * synchronised, before this call. */
 int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs, uint64_t proof_stride, size_t n_proofs,
                                 const void* d_inputs, uint64_t num_steps, const uint32_t* round_constants,
                                 size_t n_constants, const void* d_outputs, uint8_t* accept, uint8_t* status);

@@ -172,7 +172,23 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(device: int = 0) -> Context:
+def current_device() -> int:
+    """The GPU this process works on: torch's current CUDA device; for a process started by torchrun that has not
+    called torch.cuda.set_device (current device still 0), its LOCAL_RANK when the node shows that many GPUs, so that
+    the ranks of a one-process-per-GPU job do not all land on GPU 0."""
+    lr = os.environ.get("LOCAL_RANK")
+    if torch is not None and torch.cuda.is_available():
+        dev = torch.cuda.current_device()
+        if dev == 0 and lr is not None and lr.isdigit() and int(lr) < torch.cuda.device_count():
+            return int(lr)
+        return dev
+    return 0
+
+
+def default_context(device: int | None = None) -> Context:
+    """The process-wide context of `device` (None: current_device())."""
+    if device is None:
+        device = current_device()
     ctx = _default_ctx.get(device)
     if ctx is None:
         ctx = _default_ctx[device] = Context(device)

@@ -640,7 +640,8 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t c0 = 0; c0 < n_proofs;) {
         size_t c1 = c0 + 1;
-        while (c1 < n_proofs && offsets[c1 + 1] - offsets[c0] <= chunk_bytes) c1++;
+        // at most 65535 proofs per chunk: the fast path's kernels index proofs by grid.y
+        while (c1 < n_proofs && c1 - c0 < 65535 && offsets[c1 + 1] - offsets[c0] <= chunk_bytes) c1++;
         const size_t m = c1 - c0;
         std::vector<ProofWork> work(m);
         double t0 = now();

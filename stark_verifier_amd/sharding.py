@@ -19,22 +19,31 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# Tests set this to run the collectives even in a one-rank process group (the RCCL code path on a one-GPU box).
+ALWAYS_COLLECTIVE = False
+
+
 def gather_accept_bits(local_accept, total: int, device=None):
     """All ranks contribute their slice of accept flags; every rank gets the full [total] uint8 vector.
 
     Uses torch.distributed (RCCL when the process group is "nccl", gloo on CPU).  With a single
-    process (no initialised process group) it returns the input unchanged.
+    process (no initialised process group) it returns the input unchanged. RCCL only moves device
+    memory: under "nccl" the flags go through the GPU of this process (`device`, default
+    _lib.current_device()).
     """
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not ALWAYS_COLLECTIVE):
         return np.asarray(local_accept, dtype=np.uint8)
     world, rank = dist.get_world_size(), dist.get_rank()
     if isinstance(local_accept, torch.Tensor):
         t = local_accept.to(torch.uint8)
     else:
         t = torch.from_numpy(np.ascontiguousarray(local_accept, dtype=np.uint8))
+    if device is None and dist.get_backend() == "nccl" and not t.is_cuda:
+        from . import _lib
+        device = torch.device("cuda", _lib.current_device())
     if device is not None:
         t = t.to(device)
     # all_gather wants equal sizes: pad every slice to the largest one
@@ -113,7 +122,7 @@ def _all_to_all(t, group):
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (ALWAYS_COLLECTIVE and dist.is_initialized()):
         return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         src = t.cpu()

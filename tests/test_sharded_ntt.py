@@ -175,3 +175,59 @@ def test_twiddle_and_permute_kernels_against_numpy():
 @pytest.mark.gpu
 def test_two_rank_gloo_sharded_transform_hip(tmp_path):
     _run_ranks(tmp_path, 2, "hip", 14)
+
+
+NCCL_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+root_dir = sys.argv[1]
+sys.path.insert(0, root_dir); sys.path.insert(0, os.path.join(root_dir, "tests"))
+import oracle, synth
+from stark_verifier_amd import sharding
+from stark_verifier_amd.sharding import ntt_sharded, gather_accept_bits
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+sharding.ALWAYS_COLLECTIVE = True          # run all_gather / all_to_all_single over RCCL although there is one rank
+flags = np.array([1, 0, 1, 1, 0], dtype=np.uint8)
+got = gather_accept_bits(flags, 5)          # host flags in: staged through this process's GPU
+assert isinstance(got, np.ndarray) and list(got) == [1, 0, 1, 1, 0]
+got = gather_accept_bits(torch.from_numpy(flags).cuda(), 5)
+assert list(got) == [1, 0, 1, 1, 0]
+P = oracle.P
+log_n = 12
+w = pow(7, (P - 1) >> log_n, P)
+x = synth.field_elements(31337, 1 << log_n)
+for inverse in (False, True):
+    X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+    out = ntt_sharded(torch.from_numpy(x.view(np.int32).copy()).cuda(), log_n, w, inverse)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), X), inverse
+# the sharded batch helper: default context = this process's GPU, flags gathered over RCCL
+import ref_verifier as rv
+from stark_verifier_amd import batch
+good = open(os.path.join(root_dir, "tests", "golden", "proof.bin"), "rb").read()
+bad = bytearray(good); bad[len(good) // 3] ^= 2
+consts = rv.mimc_constants()
+acc, st = batch.verify_mimc_batch_sharded([good, bytes(bad), good], 3, 8192, consts, rv.mimc(3, 8192, consts))
+assert list(acc) == [1, 0, 1] and list(st) == [0, 4, 0]
+dist.barrier()
+print("ok")
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_one_rank(tmp_path):
+    """The "nccl" (RCCL) branches of the accept-flag gather and of the transform's all-to-all, forced to run in a
+    one-rank process group (a one-GPU box cannot host two RCCL ranks)."""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ok" in r.stdout
