@@ -360,67 +360,74 @@ __device__ __forceinline__ F29 f29_mul_uniform(const F29& x, const uint32_t (&b)
     return o;
 }
 
-// The product by a wave-uniform constant again, with the first operand split a = a_lo + 2^145 a_hi (limbs 0..4
-// and 5..8) and two scalar constants b and c = b * 2^145 mod p: a*b == a_lo*b + a_hi*c, whose columns reach only
-// 2^(29*12), so four high limbs are folded back instead of nine (ten multiply-adds and four limb extractions
-// fewer than f29_mul).
-__device__ __forceinline__ F29 f29_mul_uniform2(const F29& x, const uint32_t (&b)[9], const uint32_t (&c)[9]) {
-    const uint32_t* a = x.l;
-    const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1;
-    uint32_t th[5];
-    uint64_t acc = 0;
+// The product with the first operand split a = a_lo + 2^145 a_hi (limbs 0..4 and 5..8) and the second operand given
+// twice, as b and as c = b * 2^145 mod p (both tight): a*b == a_lo*b + a_hi*c, whose columns reach only 2^(29*12), so
+// four high limbs are folded back instead of nine (85 multiply-adds instead of 103 and four limb extractions fewer
+// than f29_mul). For a wave-uniform constant (the 4th root of unity, the twiddles of a round in which a wavefront's
+// lanes all run the same butterfly index) b and c sit in scalar registers: no vector registers and no load for them.
+// The body is a macro over the operand-pair constraint so that the register-only benchmark (kernbench.hip) can also
+// build the variant with per-lane second operands, which the transform does not use: inside the pass kernel the
+// second table load per twiddle costs more than the 18 multiply-adds it saves.
 #define F29_NEXT(dst)                       \
     dst = (uint32_t)acc & F29_MASK;         \
     acc >>= 29;
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) : "+v"(acc) : F29_PS(a[1], b[8]), F29_PS(a[2], b[7]), F29_PS(a[3], b[6]), F29_PS(a[4], b[5]), F29_PS(a[6], c[8]), F29_PS(a[7], c[7]), F29_PS(a[8], c[6]) : "vcc");
-    F29_NEXT(th[0])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) : "+v"(acc) : F29_PS(a[2], b[8]), F29_PS(a[3], b[7]), F29_PS(a[4], b[6]), F29_PS(a[7], c[8]), F29_PS(a[8], c[7]) : "vcc");
-    F29_NEXT(th[1])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : F29_PS(a[3], b[8]), F29_PS(a[4], b[7]), F29_PS(a[8], c[8]) : "vcc");
-    F29_NEXT(th[2])
-    asm(F29_M(1, 2) : "+v"(acc) : F29_PS(a[4], b[8]) : "vcc");
-    F29_NEXT(th[3])
-    th[4] = (uint32_t)acc;  // carry out of column 12: small
-    uint32_t r[9];
-    acc = 0;
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : F29_PS(a[0], b[0]), F29_PS(a[5], c[0]), F29_K(th[0], f0) : "vcc");
-    F29_NEXT(r[0])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) : "+v"(acc) : F29_PS(a[0], b[1]), F29_PS(a[1], b[0]), F29_PS(a[5], c[1]), F29_PS(a[6], c[0]), F29_K(th[1], f0), F29_K(th[0], f1) : "vcc");
-    F29_NEXT(r[1])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) : "+v"(acc) : F29_PS(a[0], b[2]), F29_PS(a[1], b[1]), F29_PS(a[2], b[0]), F29_PS(a[5], c[2]), F29_PS(a[6], c[1]), F29_PS(a[7], c[0]), F29_K(th[2], f0), F29_K(th[1], f1) : "vcc");
-    F29_NEXT(r[2])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) : "+v"(acc) : F29_PS(a[0], b[3]), F29_PS(a[1], b[2]), F29_PS(a[2], b[1]), F29_PS(a[3], b[0]), F29_PS(a[5], c[3]), F29_PS(a[6], c[2]), F29_PS(a[7], c[1]), F29_PS(a[8], c[0]), F29_K(th[3], f0), F29_K(th[2], f1) : "vcc");
-    F29_NEXT(r[3])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) F29_M(21, 22) : "+v"(acc) : F29_PS(a[0], b[4]), F29_PS(a[1], b[3]), F29_PS(a[2], b[2]), F29_PS(a[3], b[1]), F29_PS(a[4], b[0]), F29_PS(a[5], c[4]), F29_PS(a[6], c[3]), F29_PS(a[7], c[2]), F29_PS(a[8], c[1]), F29_K(th[4], f0), F29_K(th[3], f1) : "vcc");
-    F29_NEXT(r[4])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) : "+v"(acc) : F29_PS(a[0], b[5]), F29_PS(a[1], b[4]), F29_PS(a[2], b[3]), F29_PS(a[3], b[2]), F29_PS(a[4], b[1]), F29_PS(a[5], c[5]), F29_PS(a[6], c[4]), F29_PS(a[7], c[3]), F29_PS(a[8], c[2]), F29_K(th[4], f1) : "vcc");
-    F29_NEXT(r[5])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : F29_PS(a[0], b[6]), F29_PS(a[1], b[5]), F29_PS(a[2], b[4]), F29_PS(a[3], b[3]), F29_PS(a[4], b[2]), F29_PS(a[5], c[6]), F29_PS(a[6], c[5]), F29_PS(a[7], c[4]), F29_PS(a[8], c[3]) : "vcc");
-    F29_NEXT(r[6])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : F29_PS(a[0], b[7]), F29_PS(a[1], b[6]), F29_PS(a[2], b[5]), F29_PS(a[3], b[4]), F29_PS(a[4], b[3]), F29_PS(a[5], c[7]), F29_PS(a[6], c[6]), F29_PS(a[7], c[5]), F29_PS(a[8], c[4]) : "vcc");
-    F29_NEXT(r[7])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : F29_PS(a[0], b[8]), F29_PS(a[1], b[7]), F29_PS(a[2], b[6]), F29_PS(a[3], b[5]), F29_PS(a[4], b[4]), F29_PS(a[5], c[8]), F29_PS(a[6], c[7]), F29_PS(a[7], c[6]), F29_PS(a[8], c[5]) : "vcc");
-    F29_NEXT(r[8])
-#undef F29_NEXT
-    // second fold at 2^256: top = everything above bit 256 = (acc << 5) | (r[8] >> 24), acc below 2^36
-    uint64_t top = (acc << 5) | (uint64_t)(r[8] >> 24);
-    r[8] &= 0x00FFFFFFu;
-    uint32_t u0 = (uint32_t)top & F29_MASK, u1 = (uint32_t)(top >> 29);
-    F29 o;
-    acc = mad64(u0, F29_C0, (uint64_t)r[0]);
-    o.l[0] = (uint32_t)acc & F29_MASK;
-    acc >>= 29;
-    acc = mad64(u0, F29_C1, acc + r[1]);
-    acc = mad64(u1, F29_C0, acc);
-    o.l[1] = (uint32_t)acc & F29_MASK;
-    acc >>= 29;
-    acc = mad64(u1, F29_C1, acc + r[2]);
-    o.l[2] = (uint32_t)acc & F29_MASK;
-    o.l[3] = r[3] + (uint32_t)(acc >> 29);
-#pragma unroll
-    for (int i = 4; i < 9; i++) o.l[i] = r[i];
+#define F29_MUL_SPLIT_BODY(PAIR) \
+    const uint32_t* a = x.l; \
+    const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1; \
+    uint32_t th[5]; \
+    uint64_t acc = 0; \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) : "+v"(acc) : PAIR(a[1], b[8]), PAIR(a[2], b[7]), PAIR(a[3], b[6]), PAIR(a[4], b[5]), PAIR(a[6], c[8]), PAIR(a[7], c[7]), PAIR(a[8], c[6]) : "vcc"); \
+    F29_NEXT(th[0]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) : "+v"(acc) : PAIR(a[2], b[8]), PAIR(a[3], b[7]), PAIR(a[4], b[6]), PAIR(a[7], c[8]), PAIR(a[8], c[7]) : "vcc"); \
+    F29_NEXT(th[1]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : PAIR(a[3], b[8]), PAIR(a[4], b[7]), PAIR(a[8], c[8]) : "vcc"); \
+    F29_NEXT(th[2]) \
+    asm(F29_M(1, 2) : "+v"(acc) : PAIR(a[4], b[8]) : "vcc"); \
+    F29_NEXT(th[3]) \
+    th[4] = (uint32_t)acc; \
+    uint32_t r[9]; \
+    acc = 0; \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : PAIR(a[0], b[0]), PAIR(a[5], c[0]), F29_K(th[0], f0) : "vcc"); \
+    F29_NEXT(r[0]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) : "+v"(acc) : PAIR(a[0], b[1]), PAIR(a[1], b[0]), PAIR(a[5], c[1]), PAIR(a[6], c[0]), F29_K(th[1], f0), F29_K(th[0], f1) : "vcc"); \
+    F29_NEXT(r[1]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) : "+v"(acc) : PAIR(a[0], b[2]), PAIR(a[1], b[1]), PAIR(a[2], b[0]), PAIR(a[5], c[2]), PAIR(a[6], c[1]), PAIR(a[7], c[0]), F29_K(th[2], f0), F29_K(th[1], f1) : "vcc"); \
+    F29_NEXT(r[2]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) : "+v"(acc) : PAIR(a[0], b[3]), PAIR(a[1], b[2]), PAIR(a[2], b[1]), PAIR(a[3], b[0]), PAIR(a[5], c[3]), PAIR(a[6], c[2]), PAIR(a[7], c[1]), PAIR(a[8], c[0]), F29_K(th[3], f0), F29_K(th[2], f1) : "vcc"); \
+    F29_NEXT(r[3]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) F29_M(21, 22) : "+v"(acc) : PAIR(a[0], b[4]), PAIR(a[1], b[3]), PAIR(a[2], b[2]), PAIR(a[3], b[1]), PAIR(a[4], b[0]), PAIR(a[5], c[4]), PAIR(a[6], c[3]), PAIR(a[7], c[2]), PAIR(a[8], c[1]), F29_K(th[4], f0), F29_K(th[3], f1) : "vcc"); \
+    F29_NEXT(r[4]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) : "+v"(acc) : PAIR(a[0], b[5]), PAIR(a[1], b[4]), PAIR(a[2], b[3]), PAIR(a[3], b[2]), PAIR(a[4], b[1]), PAIR(a[5], c[5]), PAIR(a[6], c[4]), PAIR(a[7], c[3]), PAIR(a[8], c[2]), F29_K(th[4], f1) : "vcc"); \
+    F29_NEXT(r[5]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : PAIR(a[0], b[6]), PAIR(a[1], b[5]), PAIR(a[2], b[4]), PAIR(a[3], b[3]), PAIR(a[4], b[2]), PAIR(a[5], c[6]), PAIR(a[6], c[5]), PAIR(a[7], c[4]), PAIR(a[8], c[3]) : "vcc"); \
+    F29_NEXT(r[6]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : PAIR(a[0], b[7]), PAIR(a[1], b[6]), PAIR(a[2], b[5]), PAIR(a[3], b[4]), PAIR(a[4], b[3]), PAIR(a[5], c[7]), PAIR(a[6], c[6]), PAIR(a[7], c[5]), PAIR(a[8], c[4]) : "vcc"); \
+    F29_NEXT(r[7]) \
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) : "+v"(acc) : PAIR(a[0], b[8]), PAIR(a[1], b[7]), PAIR(a[2], b[6]), PAIR(a[3], b[5]), PAIR(a[4], b[4]), PAIR(a[5], c[8]), PAIR(a[6], c[7]), PAIR(a[7], c[6]), PAIR(a[8], c[5]) : "vcc"); \
+    F29_NEXT(r[8]) \
+    uint64_t top = (acc << 5) | (uint64_t)(r[8] >> 24); \
+    r[8] &= 0x00FFFFFFu; \
+    uint32_t u0 = (uint32_t)top & F29_MASK, u1 = (uint32_t)(top >> 29); \
+    F29 o; \
+    acc = mad64(u0, F29_C0, (uint64_t)r[0]); \
+    o.l[0] = (uint32_t)acc & F29_MASK; \
+    acc >>= 29; \
+    acc = mad64(u0, F29_C1, acc + r[1]); \
+    acc = mad64(u1, F29_C0, acc); \
+    o.l[1] = (uint32_t)acc & F29_MASK; \
+    acc >>= 29; \
+    acc = mad64(u1, F29_C1, acc + r[2]); \
+    o.l[2] = (uint32_t)acc & F29_MASK; \
+    o.l[3] = r[3] + (uint32_t)(acc >> 29); \
+    _Pragma("unroll") \
+    for (int i = 4; i < 9; i++) o.l[i] = r[i]; \
     return o;
+
+__device__ __forceinline__ F29 f29_mul_uniform2(const F29& x, const uint32_t (&b)[9], const uint32_t (&c)[9]) {
+    F29_MUL_SPLIT_BODY(F29_PS)
 }
+
+#undef F29_NEXT
 
 // Lazy -> tight without a multiplication: one carry pass that also folds what lies above bit 256 (taken
 // from limb 8 before the carries below it arrive): e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8, entered as

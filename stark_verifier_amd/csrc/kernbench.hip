@@ -94,6 +94,51 @@ __global__ void __launch_bounds__(256) k_femul29(Stamp* st, uint32_t* sink, uint
     if (acc == 0x1234567) sink[0] = acc;
 }
 
+// per-lane operands of the split product: y = b, y2 = b * 2^145 mod p (benchmark only, see field29.cuh)
+#define F29_NEXT(dst)                       \
+    dst = (uint32_t)acc & F29_MASK;         \
+    acc >>= 29;
+__device__ __forceinline__ F29 f29_mul_split(const F29& x, const F29& y, const F29& y2) {
+    const uint32_t* b = y.l;
+    const uint32_t* c = y2.l;
+    F29_MUL_SPLIT_BODY(F29_P)
+}
+#undef F29_NEXT
+
+// the split product with per-lane second operands (b, b * 2^145): 85 multiply-adds
+__global__ void __launch_bounds__(256) k_femul29_split(Stamp* st, uint32_t* sink, uint32_t s) {
+    F29 a = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), b = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
+    F29 c = f29_from_fe(fe_canon(seed_fe(s * 7 + blockIdx.x)));
+    unsigned long long c0, r0;
+    stamp_begin(c0, r0);
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) a = f29_mul_split(a, b, c);
+    stamp_end(st, c0, r0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 9; i++) acc ^= a.l[i];
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+// the same with the second operands in scalar registers (a wave-uniform constant)
+__global__ void __launch_bounds__(256) k_femul29_uniform(Stamp* st, uint32_t* sink, uint32_t s) {
+    F29 a = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x)));
+    uint32_t b[9], c[9];
+    for (int i = 0; i < 9; i++) {
+        b[i] = __builtin_amdgcn_readfirstlane((s * (i + 3) + blockIdx.x * 77u) & F29_MASK);
+        c[i] = __builtin_amdgcn_readfirstlane((s * (i + 11) + blockIdx.x * 131u) & F29_MASK);
+    }
+    b[8] &= 0xFFFFFFu;
+    c[8] &= 0xFFFFFFu;
+    unsigned long long c0, r0;
+    stamp_begin(c0, r0);
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) a = f29_mul_uniform2(a, b, c);
+    stamp_end(st, c0, r0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 9; i++) acc ^= a.l[i];
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
 __global__ void __launch_bounds__(256) k_butterfly29(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 x = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), y = f29_from_fe(fe_canon(seed_fe(s * 5 + threadIdx.x)));
     F29 w = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
@@ -174,6 +219,8 @@ int main(int argc, char** argv) {
     run("fe_mul", k_femul, blocks, d_st, h_st, d_sink);
     run("butterfly", k_butterfly, blocks, d_st, h_st, d_sink);
     run("f29_mul", k_femul29, blocks, d_st, h_st, d_sink);
+    run("f29_mul_split", k_femul29_split, blocks, d_st, h_st, d_sink);
+    run("f29_mul_unif2", k_femul29_uniform, blocks, d_st, h_st, d_sink);
     run("butterfly29", k_butterfly29, blocks, d_st, h_st, d_sink);
     run("blake2s", k_blake2s, blocks, d_st, h_st, d_sink);
     return 0;
