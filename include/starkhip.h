@@ -113,7 +113,7 @@ int stark_ntt_batch_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned 
  * them with events). Nothing in the array has to be cleared between calls: every word a pass reads was written by
  * the pass before it in the same call.
  */
-#define STARK_STATIC_SCRATCH_BYTES ((size_t)48 << 20) /* 2^20 points x 48 bytes */
+#define STARK_STATIC_SCRATCH_BYTES ((size_t)36 << 20) /* 2^20 points x 36 bytes of intermediate */
 #define STARK_STATIC_MAX_LOG_N 20
 int stark_ntt_batch_dev_static(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t batch,
                                const uint32_t root_of_unity[8], int inverse, void* stream);

@@ -569,7 +569,7 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
         return STARK_OK;
     }
     // multi-pass: first pass into scratch, middle pass in place there, last pass to d_out
-    const size_t mid_bytes = 48;  // bytes per element of the intermediate (nine unpacked limbs, padded)
+    const size_t mid_bytes = ntt29_mid_bytes();  // bytes per element of the intermediate (nine unpacked limbs)
     size_t chunk = ctx->chunk_bytes / (n * 32);
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;

@@ -235,131 +235,6 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
     return o;
 }
 
-// The same product with the tight operand held in scalar registers (a wave-uniform constant such as the
-// 4th root of unity): no vector registers and no load for it.
-__device__ __forceinline__ F29 f29_mul_uniform(const F29& x, const uint32_t (&b)[9]) {
-    const uint32_t* a = x.l;
-    const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1;
-    // columns 9..16 first: their 29-bit limbs th[0..8] sit at 2^261 * 2^(29 k)
-    uint32_t th[9];
-    uint64_t acc = 0;
-#define F29_NEXT(dst)                     \
-    dst = (uint32_t)acc & F29_MASK;         \
-    acc >>= 29;
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-        : "+v"(acc)
-        : F29_PS(a[1], b[8]), F29_PS(a[2], b[7]), F29_PS(a[3], b[6]), F29_PS(a[4], b[5]), F29_PS(a[5], b[4]),
-          F29_PS(a[6], b[3]), F29_PS(a[7], b[2]), F29_PS(a[8], b[1])
-        : "vcc");
-    F29_NEXT(th[0])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14)
-        : "+v"(acc)
-        : F29_PS(a[2], b[8]), F29_PS(a[3], b[7]), F29_PS(a[4], b[6]), F29_PS(a[5], b[5]), F29_PS(a[6], b[4]),
-          F29_PS(a[7], b[3]), F29_PS(a[8], b[2])
-        : "vcc");
-    F29_NEXT(th[1])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
-        : "+v"(acc)
-        : F29_PS(a[3], b[8]), F29_PS(a[4], b[7]), F29_PS(a[5], b[6]), F29_PS(a[6], b[5]), F29_PS(a[7], b[4]),
-          F29_PS(a[8], b[3])
-        : "vcc");
-    F29_NEXT(th[2])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
-        : "+v"(acc)
-        : F29_PS(a[4], b[8]), F29_PS(a[5], b[7]), F29_PS(a[6], b[6]), F29_PS(a[7], b[5]), F29_PS(a[8], b[4])
-        : "vcc");
-    F29_NEXT(th[3])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
-        : "+v"(acc)
-        : F29_PS(a[5], b[8]), F29_PS(a[6], b[7]), F29_PS(a[7], b[6]), F29_PS(a[8], b[5])
-        : "vcc");
-    F29_NEXT(th[4])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : F29_PS(a[6], b[8]), F29_PS(a[7], b[7]), F29_PS(a[8], b[6]) : "vcc");
-    F29_NEXT(th[5])
-    asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_PS(a[7], b[8]), F29_PS(a[8], b[7]) : "vcc");
-    F29_NEXT(th[6])
-    asm(F29_M(1, 2) : "+v"(acc) : F29_PS(a[8], b[8]) : "vcc");
-    F29_NEXT(th[7])
-    th[8] = (uint32_t)acc;  // below 2^27
-    // columns 0..8 with the high limbs folded in: 2^261 * t == (FOLD1 * 2^29 + FOLD0) * t
-    uint32_t r[9];
-    acc = 0;
-    asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_PS(a[0], b[0]), F29_K(th[0], f0) : "vcc");
-    F29_NEXT(r[0])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
-        : "+v"(acc)
-        : F29_PS(a[0], b[1]), F29_PS(a[1], b[0]), F29_K(th[1], f0), F29_K(th[0], f1)
-        : "vcc");
-    F29_NEXT(r[1])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
-        : "+v"(acc)
-        : F29_PS(a[0], b[2]), F29_PS(a[1], b[1]), F29_PS(a[2], b[0]), F29_K(th[2], f0), F29_K(th[1], f1)
-        : "vcc");
-    F29_NEXT(r[2])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
-        : "+v"(acc)
-        : F29_PS(a[0], b[3]), F29_PS(a[1], b[2]), F29_PS(a[2], b[1]), F29_PS(a[3], b[0]), F29_K(th[3], f0),
-          F29_K(th[2], f1)
-        : "vcc");
-    F29_NEXT(r[3])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14)
-        : "+v"(acc)
-        : F29_PS(a[0], b[4]), F29_PS(a[1], b[3]), F29_PS(a[2], b[2]), F29_PS(a[3], b[1]), F29_PS(a[4], b[0]),
-          F29_K(th[4], f0), F29_K(th[3], f1)
-        : "vcc");
-    F29_NEXT(r[4])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-        : "+v"(acc)
-        : F29_PS(a[0], b[5]), F29_PS(a[1], b[4]), F29_PS(a[2], b[3]), F29_PS(a[3], b[2]), F29_PS(a[4], b[1]),
-          F29_PS(a[5], b[0]), F29_K(th[5], f0), F29_K(th[4], f1)
-        : "vcc");
-    F29_NEXT(r[5])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-            F29_M(17, 18)
-        : "+v"(acc)
-        : F29_PS(a[0], b[6]), F29_PS(a[1], b[5]), F29_PS(a[2], b[4]), F29_PS(a[3], b[3]), F29_PS(a[4], b[2]),
-          F29_PS(a[5], b[1]), F29_PS(a[6], b[0]), F29_K(th[6], f0), F29_K(th[5], f1)
-        : "vcc");
-    F29_NEXT(r[6])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-            F29_M(17, 18) F29_M(19, 20)
-        : "+v"(acc)
-        : F29_PS(a[0], b[7]), F29_PS(a[1], b[6]), F29_PS(a[2], b[5]), F29_PS(a[3], b[4]), F29_PS(a[4], b[3]),
-          F29_PS(a[5], b[2]), F29_PS(a[6], b[1]), F29_PS(a[7], b[0]), F29_K(th[7], f0), F29_K(th[6], f1)
-        : "vcc");
-    F29_NEXT(r[7])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-            F29_M(17, 18) F29_M(19, 20) F29_M(21, 22)
-        : "+v"(acc)
-        : F29_PS(a[0], b[8]), F29_PS(a[1], b[7]), F29_PS(a[2], b[6]), F29_PS(a[3], b[5]), F29_PS(a[4], b[4]),
-          F29_PS(a[5], b[3]), F29_PS(a[6], b[2]), F29_PS(a[7], b[1]), F29_PS(a[8], b[0]), F29_K(th[8], f0),
-          F29_K(th[7], f1)
-        : "vcc");
-    F29_NEXT(r[8])
-#undef F29_NEXT
-    acc = mad64(th[8], F29_FOLD1, acc);  // what remains at 2^261: below 2^45
-    // second fold at 2^256: top = everything above bit 256 = (acc << 5) | (r[8] >> 24)
-    uint64_t top = (acc << 5) | (uint64_t)(r[8] >> 24);
-    r[8] &= 0x00FFFFFFu;
-    uint32_t u0 = (uint32_t)top & F29_MASK, u1 = (uint32_t)(top >> 29);  // u1 < 2^21
-    F29 o;
-    acc = mad64(u0, F29_C0, (uint64_t)r[0]);
-    o.l[0] = (uint32_t)acc & F29_MASK;
-    acc >>= 29;
-    acc = mad64(u0, F29_C1, acc + r[1]);
-    acc = mad64(u1, F29_C0, acc);
-    o.l[1] = (uint32_t)acc & F29_MASK;
-    acc >>= 29;
-    acc = mad64(u1, F29_C1, acc + r[2]);
-    o.l[2] = (uint32_t)acc & F29_MASK;
-    // what is left above limb 2 is below 2^5 (u1*C1 < 2^33, shifted down by 29): it stays in limb 3
-    // unpropagated, which every consumer of a tight value tolerates
-    o.l[3] = r[3] + (uint32_t)(acc >> 29);
-#pragma unroll
-    for (int i = 4; i < 9; i++) o.l[i] = r[i];
-    return o;
-}
-
 // The product with the first operand split a = a_lo + 2^145 a_hi (limbs 0..4 and 5..8) and the second operand given
 // twice, as b and as c = b * 2^145 mod p (both tight): a*b == a_lo*b + a_hi*c, whose columns reach only 2^(29*12), so
 // four high limbs are folded back instead of nine (85 multiply-adds instead of 103 and four limb extractions fewer

@@ -67,6 +67,8 @@ struct NttPassArgs {
 
 // W entries are 12 unpacked dwords
 size_t ntt29_pass_lds_bytes(int log_t, int log_c);
+// bytes per element of the multi-pass intermediate (nine unpacked limbs)
+size_t ntt29_mid_bytes();
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
 hipError_t launch_unpack_table(const uint32_t* in, uint32_t* out, size_t count, hipStream_t stream);
 // ---- tables.hip ----

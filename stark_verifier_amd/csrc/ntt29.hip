@@ -20,8 +20,8 @@
 //     element is nine adjacent dwords;
 //   * butterfly additions and subtractions are limb-wise v_add_u32 / v_sub_u32 with no carry
 //     chain, the products are carry-free v_mad_u64_u32 columns (field29.cuh);
-//   * between passes of a multi-pass transform the intermediate stays unpacked (12 dwords per
-//     element, 16-byte aligned), so only the first load and the last store convert; the last
+//   * between passes of a multi-pass transform the intermediate stays unpacked (nine dwords per
+//     element, back to back), so only the first load and the last store convert; the last
 //     store reduces to the canonical residue and repacks.
 // Tile twiddles W are stored unpacked (12 dwords per entry); the large inter-pass table TW
 // stays packed (8 dwords) and is unpacked on load.
@@ -53,7 +53,7 @@ __device__ __forceinline__ F29 lds_get29(const uint32_t* lds, uint32_t off) {
     return v;
 }
 
-// unpacked element in global memory: 12 dwords (limbs 0..8, three unused)
+// unpacked table entry in global memory: 12 dwords (limbs 0..8, three unused), 16-byte aligned
 __device__ __forceinline__ F29 f29_load_raw(const uint32_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
@@ -62,6 +62,31 @@ __device__ __forceinline__ F29 f29_load_raw(const uint32_t* p) {
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
     r.l[8] = p[8];  // one dword: the three padding dwords are never fetched into registers
     return r;
+}
+
+// unpacked element of the multi-pass intermediate: nine dwords, elements back to back (36 bytes; a padded 48-byte
+// element costs 15 % more memory traffic and is no faster, measured)
+constexpr uint32_t RAW_W = 9;
+struct __attribute__((aligned(4))) U3 {
+    uint32_t x, y, z;
+};
+
+// three 12-byte accesses: an element starts on a multiple of 4 bytes only
+__device__ __forceinline__ F29 f29_load_mid(const uint32_t* p) {
+    const U3* q = reinterpret_cast<const U3*>(p);
+    const U3 a = q[0], b = q[1], c = q[2];
+    F29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z;
+    r.l[3] = b.x; r.l[4] = b.y; r.l[5] = b.z;
+    r.l[6] = c.x; r.l[7] = c.y; r.l[8] = c.z;
+    return r;
+}
+
+__device__ __forceinline__ void f29_store_mid(uint32_t* p, const F29& v) {
+    U3* q = reinterpret_cast<U3*>(p);
+    q[0] = U3{v.l[0], v.l[1], v.l[2]};
+    q[1] = U3{v.l[3], v.l[4], v.l[5]};
+    q[2] = U3{v.l[6], v.l[7], v.l[8]};
 }
 
 __device__ __forceinline__ void f29_store_raw(uint32_t* p, const F29& v) {
@@ -92,6 +117,8 @@ __host__ __device__ inline uint32_t tile_pad29(uint32_t log_c) {
     if (log_c == 0) return 0;
     return log_c >= 5 ? 1u : (32u >> log_c);
 }
+
+size_t ntt29_mid_bytes() { return 4 * RAW_W; }
 
 size_t ntt29_pass_lds_bytes(int log_t, int log_c) {
     const int lw = log_t > 8 ? log_t - 8 : 0;
@@ -127,7 +154,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     const uint32_t log_c = a.log_c, C = 1u << log_c;
     const uint32_t Tp = G::ROW + tile_pad29(log_c);
     const uint32_t tid = threadIdx.x;
-    const uint32_t in_w = a.in_raw ? 12u : 8u, out_w = a.out_raw ? 12u : 8u;
+    const uint32_t in_w = a.in_raw ? RAW_W : 8u, out_w = a.out_raw ? RAW_W : 8u;
     // Work item -> (tile, polynomial). Workgroups are dealt round-robin over the 8 XCDs, each with
     // its own L2. With the grouped order, the workgroups that share an L2 take 2^grp_log adjacent
     // tiles (whose strided 64..96-byte pieces complete each other's 128-byte lines) of every
@@ -180,10 +207,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
             const uint64_t s = (uint64_t)in_w * a.inS;
             if (a.in_raw) {
-                x0 = f29_load_raw(src + s * j);
-                x1 = f29_load_raw(src + s * (j + Q));
-                x2 = f29_load_raw(src + s * (j + 2 * Q));
-                x3 = f29_load_raw(src + s * (j + 3 * Q));
+                x0 = f29_load_mid(src + s * j);
+                x1 = f29_load_mid(src + s * (j + Q));
+                x2 = f29_load_mid(src + s * (j + 2 * Q));
+                x3 = f29_load_mid(src + s * (j + 3 * Q));
             } else {
                 x0 = f29_from_fe(fe_load(src + s * j));
                 x1 = f29_from_fe(fe_load(src + s * (j + Q)));
@@ -333,10 +360,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             uint32_t* dst = a.out + out_w * (poly + hi * a.outA + lo * a.outB + c * a.outC);
             const uint64_t s = (uint64_t)out_w * a.outS;
             if (a.out_raw) {
-                f29_store_raw(dst + s * j, y0);
-                f29_store_raw(dst + s * (j + Q), y1);
-                f29_store_raw(dst + s * (j + 2 * Q), y2);
-                f29_store_raw(dst + s * (j + 3 * Q), y3);
+                f29_store_mid(dst + s * j, y0);
+                f29_store_mid(dst + s * (j + Q), y1);
+                f29_store_mid(dst + s * (j + 2 * Q), y2);
+                f29_store_mid(dst + s * (j + 3 * Q), y3);
             } else {
                 fe_store(dst + s * j, f29_to_fe(y0));
                 fe_store(dst + s * (j + Q), f29_to_fe(y1));
