@@ -142,6 +142,43 @@ int stark_twiddle_mul_dev(stark_ctx* ctx, void* d_data, size_t rows, size_t cols
  * received ones. d_in and d_out must not overlap; a <= 2097120 when chunk == 1. */
 int stark_permute3_dev(stark_ctx* ctx, const void* d_in, void* d_out, size_t a, size_t b, size_t chunk, void* stream);
 
+/*
+ * The same transform with the three steps fused into two device calls, for hosts that drive the exchange themselves
+ * (RCCL grouped send/recv or ncclAllToAll on their own communicator) or hand it in as a callback. No counterpart in
+ * the reference. n = 2^log_n = n1 * n2 with n1 = 2^(log_n / 2); `world` ranks (a power of two that divides n1 and
+ * n2), r1 = n1 / world, r2 = n2 / world. Per rank, all buffers hold n / world elements:
+ *   d_in   "rows"    [r1][n2]         element (a, j2)  = x[(rank * r1 + a) + n1 * j2]
+ *   d_send           [world][r1][r2]  block d goes to rank d; d_recv [world][r1][r2], block s came from rank s
+ *   d_out  "columns" [n1][r2]         element (k1, b)  = X[k1 * n2 + rank * r2 + b]
+ * Stage A: the r1 row transforms (n2 points, root^n1), each output (a, k2) multiplied by root^(+-(rank * r1 + a) * k2)
+ * in the last pass's store and written straight into the send block of the rank that owns k2. Stage C: the r2 column
+ * transforms (n1 points, root^n2) of the received [n1][r2] matrix, columns adjacent in memory. X = the transform of x
+ * with fft_inv semantics when inverse != 0 (reference src/fft.rs:64-86), else the forward transform (_fft, :37-61).
+ * STARK_ERR_UNSUPPORTED below 2^4 points or when world is too large for the fused store (r2 below the last pass's
+ * tile count): use the three-step form above.
+ */
+int stark_ntt_sharded_stage_a_dev(stark_ctx* ctx, const void* d_in, void* d_send, unsigned log_n, unsigned world,
+                                  unsigned rank, const uint32_t root_of_unity[8], int inverse, void* stream);
+int stark_ntt_sharded_stage_c_dev(stark_ctx* ctx, const void* d_recv, void* d_out, unsigned log_n, unsigned world,
+                                  const uint32_t root_of_unity[8], int inverse, void* stream);
+
+/* Equal-block all-to-all on device memory, queued on `stream`: block d of d_send (block_bytes each, `world` blocks)
+ * goes to rank d, block s of d_recv comes from rank s. Returns 0 on success. */
+typedef int (*stark_all_to_all_fn)(void* user, const void* d_send, void* d_recv, size_t block_bytes, void* stream);
+
+/* Stage A, exchange(user, ...), stage C in one call. d_x holds the "rows" input and is overwritten; d_y is the other
+ * n / world element buffer. The "columns" result is left in d_y when world > 1 and in d_x when world == 1 (no
+ * exchange is called then). Queued on `stream` (NULL = the context's stream); does not synchronise. */
+int stark_ntt_sharded_dev(stark_ctx* ctx, void* d_x, void* d_y, unsigned log_n, unsigned world, unsigned rank,
+                          const uint32_t root_of_unity[8], int inverse, stark_all_to_all_fn exchange, void* user,
+                          void* stream);
+
+/* Transforms of the `cols` columns of a row-major [2^log_n][cols] matrix of elements (column c = elements c,
+ * c + cols, c + 2 cols, ...): `cols` interleaved polynomials, the layout stage C works on. cols a power of two,
+ * 4 <= 2^log_n <= 2^24; d_in and d_out may be equal. Same semantics per column as stark_ntt_batch_dev. */
+int stark_ntt_columns_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t cols,
+                          const uint32_t root_of_unity[8], int inverse, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Merkle — replaces the bodies of ProofBranch::verify (reference src/merkle_tree.rs:119-171)
  * and the loop of MultiProof::verify (src/merkle_tree.rs:25-44).

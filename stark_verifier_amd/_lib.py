@@ -33,7 +33,13 @@ EXPORTS = [
     "stark_merkle_build", "stark_merkle_build_dev",
     "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev", "stark_mimc_batch", "stark_mimc_batch_dev",
     "stark_mimc_verify_batch_diag", "stark_ntt_batch_dev_static",
+    "stark_ntt_sharded_stage_a_dev", "stark_ntt_sharded_stage_c_dev", "stark_ntt_sharded_dev", "stark_ntt_columns_dev",
 ]
+
+
+# int (*stark_all_to_all_fn)(void* user, const void* d_send, void* d_recv, size_t block_bytes, void* stream)
+ALL_TO_ALL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                 ctypes.c_void_p)
 
 
 class StarkError(RuntimeError):
@@ -80,6 +86,14 @@ def load() -> ctypes.CDLL:
     L.stark_ntt_batch_dev.restype = i32
     L.stark_ntt_batch_dev_static.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
     L.stark_ntt_batch_dev_static.restype = i32
+    L.stark_ntt_sharded_stage_a_dev.argtypes = [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp, i32, vp]
+    L.stark_ntt_sharded_stage_a_dev.restype = i32
+    L.stark_ntt_sharded_stage_c_dev.argtypes = [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp, i32, vp]
+    L.stark_ntt_sharded_stage_c_dev.restype = i32
+    L.stark_ntt_sharded_dev.argtypes = [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp, i32, ALL_TO_ALL_FN, vp, vp]
+    L.stark_ntt_sharded_dev.restype = i32
+    L.stark_ntt_columns_dev.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
+    L.stark_ntt_columns_dev.restype = i32
     L.stark_merkle_verify_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, u32, vp, sz, vp, vp]
     L.stark_merkle_verify_batch.restype = i32
     L.stark_merkle_verify_batch_dev.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, vp, sz, vp, vp, vp]

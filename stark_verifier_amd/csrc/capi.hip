@@ -43,6 +43,7 @@ struct NttPlan {
     bool tiny = false;  // n <= 2
     uint32_t scale[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     int has_scale = 0;
+    uint64_t cols = 0;        // column plans: columns of the matrix; stage A tables: world << 32 | rank
     size_t table_bytes = 0;   // device memory held by `tables`
     uint64_t last_use = 0;    // for least-recently-used eviction
 };
@@ -55,6 +56,8 @@ struct stark_ctx {
     std::string err;
     std::vector<std::unique_ptr<NttPlan>> plans;
     std::vector<std::unique_ptr<NttPlan>> shard_tables;  // two-level power tables of stark_twiddle_mul_dev (passes unused)
+    std::vector<std::unique_ptr<NttPlan>> col_plans;     // column transforms of a row-major matrix (cols in NttPlan::cols)
+    std::vector<std::unique_ptr<NttPlan>> stage_a_tabs;  // twiddle tables of stark_ntt_sharded_stage_a_dev (passes unused)
     void* scratch = nullptr;  // multi-pass intermediate
     size_t scratch_bytes = 0;
     void* static_scratch = nullptr;  // device address of g_static_scratch on this context's device
@@ -246,8 +249,9 @@ int choose_log_c(int log_t, unsigned log_extent, int target_threads) {
     return log_c;
 }
 
+// out[i] = scale * base^((row0 + i / row_len) * (i % row_len)), or scale * base^i when row_len == 0
 int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, uint64_t row_len, const U256& scale,
-               uint32_t** out, bool unpack = false) {
+               uint32_t** out, bool unpack = false, uint64_t row0 = 0) {
     uint32_t pw[64 * 8];
     U256 b = base;
     for (int k = 0; k < 64; k++) {
@@ -267,7 +271,7 @@ int make_table(stark_ctx* ctx, NttPlan* plan, const U256& base, size_t count, ui
     uint32_t sc[8];
     hostfe::to_limbs(scale, sc);
     e = hipMemcpyAsync(d_pw, pw, sizeof pw, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = launch_fill_powers((uint32_t*)d_tab, count, row_len, (const uint32_t*)d_pw, sc, ctx->stream);
+    if (e == hipSuccess) e = launch_fill_powers((uint32_t*)d_tab, count, row_len, row0, (const uint32_t*)d_pw, sc, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_pw);
     if (e != hipSuccess) return fail(ctx, STARK_ERR_HIP, "twiddle table build: %s", hipGetErrorString(e));
@@ -545,8 +549,18 @@ bool has_order(const U256& root, unsigned log_n) {
 }
 
 // fixed != nullptr: the multi-pass intermediate goes to that buffer of fixed_bytes and nothing is allocated
+// What the last pass of a plan does differently when it is stage A of a transform sharded over several GPUs: every
+// output is multiplied by a table entry and stored into the send block of the rank that owns it.
+struct LastPassOverride {
+    const uint32_t* TW = nullptr;  // [polynomial][output index], polynomial stride tw_poly elements
+    uint64_t tw_poly = 0;
+    uint64_t out_poly = 0;         // polynomial stride of the output
+    uint32_t ksh = 31;             // output index k goes to (k >> ksh) * outS2 + (k & (2^ksh - 1))
+    uint64_t outS2 = 0;
+};
+
 int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_out, size_t batch, hipStream_t stream,
-             void* fixed = nullptr, size_t fixed_bytes = 0) {
+             void* fixed = nullptr, size_t fixed_bytes = 0, const LastPassOverride* ov = nullptr) {
     const uint64_t n = (uint64_t)1 << plan->log_n;
     if (batch == 0) return STARK_OK;
     if (plan->tiny) {
@@ -564,6 +578,20 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.in = d_in + 8 * n * done;
             a.out = d_out + 8 * n * done;
             a.c_limit = cnt;
+            a.ksh = 31;
+            a.kmask = 0xFFFFFFFFu;
+            if (ov) {  // polynomials are folded into the tile index here: lo * C + c
+                a.out = d_out + 8 * ov->out_poly * done;
+                a.outB = ov->out_poly << a.log_c;
+                a.outC = ov->out_poly;
+                a.TW = ov->TW + 8 * ov->tw_poly * done;
+                a.twB = ov->tw_poly << a.log_c;
+                a.twC = ov->tw_poly;
+                a.twS = 1;
+                a.ksh = ov->ksh;
+                a.kmask = (1u << ov->ksh) - 1u;
+                a.outS2 = ov->outS2;
+            }
             HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, (unsigned)((cnt + C - 1) / C), 1, stream));
         }
         return STARK_OK;
@@ -595,6 +623,26 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.out = k + 1 == plan->passes.size() ? d_out + 8 * n * done : tmp;
             a.in_raw = k > 0;
             a.out_raw = k + 1 < plan->passes.size();
+            a.outP = a.poly_stride;
+            a.ksh = 31;
+            a.kmask = 0xFFFFFFFFu;
+            if (ov && k + 1 == plan->passes.size()) {
+                // the last pass stores output index o = k1 + n1' * k (outS = n1'); the split point 2^ksh of o is at or
+                // above n1' (checked by the caller), so it splits k alone
+                unsigned log_s = 0;
+                while (((uint64_t)1 << log_s) < a.outS) log_s++;
+                a.out = d_out + 8 * ov->out_poly * done;
+                a.outP = ov->out_poly;
+                a.TW = ov->TW + 8 * ov->tw_poly * done;
+                a.twP = ov->tw_poly;
+                a.twA = a.outA;
+                a.twB = a.outB;
+                a.twC = a.outC;
+                a.twS = a.outS;
+                a.ksh = ov->ksh - log_s;
+                a.kmask = (1u << a.ksh) - 1u;
+                a.outS2 = ov->outS2;
+            }
             HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, (unsigned)cnt, stream));
         }
     }
@@ -613,6 +661,162 @@ int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, si
     return run_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_out, batch, stream);
 }
 
+// ---- column transforms of a row-major [2^log_n][cols] matrix (cols a power of two) ------------------------------
+// Every column is one polynomial (element stride cols, polynomial stride 1): what stage C of a sharded transform
+// needs, where the matrix is the [n1][n2 / world] block the all-to-all leaves on a rank. Adjacent columns are adjacent
+// in memory, so a workgroup takes C adjacent columns of one tile position and every global access is a run of C
+// elements. Up to 2^6 rows: one pass. Above: two passes, rows i = k1-major index split N = N1 * M as in build_plan, with
+// the matrix seen as [N1][M * cols] (pass 1: columns of that matrix) and as [N1][M][cols] (pass 2: over M).
+int build_col_plan(stark_ctx* ctx, unsigned log_n, uint64_t cols, const U256& root, bool inverse, NttPlan** out) {
+    std::unique_ptr<NttPlan> plan(new NttPlan);
+    plan->log_n = log_n;
+    plan->root = root;
+    plan->inverse = inverse;
+    plan->cols = cols;
+    const uint64_t N = (uint64_t)1 << log_n;
+    const U256 w = inverse ? hostfe::pow_u64(root, N - 1) : root;
+    const U256 scale = inverse ? hostfe::inverse(hostfe::from_u64(N)) : hostfe::from_u64(1);
+    const U256 one = hostfe::from_u64(1);
+    hostfe::to_limbs(scale, plan->scale);
+    plan->has_scale = inverse;
+    unsigned log_cols = 0;
+    while (((uint64_t)1 << log_cols) < cols) log_cols++;
+    const int target_threads = env_int("STARKHIP_THREADS", 512);
+    int rc;
+    auto fail_free = [&](int code) {
+        free_plan(plan.get());
+        return code;
+    };
+    if (log_n <= 6) {
+        PassPlan p;
+        p.log_t = (int)log_n;
+        NttPassArgs& a = p.args;
+        a.log_c = choose_log_c((int)log_n, log_cols, target_threads);
+        const uint64_t C = (uint64_t)1 << a.log_c;
+        a.dsh = 31;
+        a.dmask = 0xFFFFFFFFu;
+        a.inB = a.outB = C;
+        a.inC = a.outC = 1;
+        a.inS = a.outS = cols;
+        a.c_limit = ~0ull;
+        a.load_cfast = a.store_cfast = 1;
+        a.canon_in = 1;
+        a.has_scale = plan->has_scale;
+        memcpy(a.scale, plan->scale, sizeof a.scale);
+        uint32_t* W;
+        if ((rc = make_table(ctx, plan.get(), w, N, 0, one, &W, true)) != STARK_OK) return fail_free(rc);
+        a.W = W;
+        set_quarter_root(a, w, (int)log_n);
+        p.tiles = (unsigned)(cols >> a.log_c);
+        plan->passes.push_back(p);
+    } else {
+        const int l1 = (int)log_n / 2, l2 = (int)log_n - l1;
+        const uint64_t N1 = (uint64_t)1 << l1, M = (uint64_t)1 << l2;
+        const U256 w1 = hostfe::pow_u64(w, M), w2 = hostfe::pow_u64(w, N1);
+        uint32_t *W1, *W2, *TW;
+        if ((rc = make_table(ctx, plan.get(), w1, N1, 0, one, &W1, true)) != STARK_OK ||
+            (rc = make_table(ctx, plan.get(), w2, M, 0, one, &W2, true)) != STARK_OK ||
+            (rc = make_table(ctx, plan.get(), w, N, M, scale, &TW)) != STARK_OK)
+            return fail_free(rc);
+        {
+            PassPlan p;  // tile (j, column group): rows k1 at stride M * cols
+            p.log_t = l1;
+            NttPassArgs& a = p.args;
+            a.log_c = choose_log_c(l1, log_cols, target_threads);
+            const uint64_t C = (uint64_t)1 << a.log_c;
+            a.dsh = log_cols - a.log_c;
+            a.dmask = (uint32_t)((cols >> a.log_c) - 1);
+            a.inA = a.outA = cols;
+            a.inB = a.outB = C;
+            a.inC = a.outC = 1;
+            a.inS = a.outS = M * cols;
+            a.twA = 1;
+            a.twS = M;
+            a.c_limit = ~0ull;
+            a.load_cfast = a.store_cfast = 1;
+            a.canon_in = 1;
+            a.W = W1;
+            set_quarter_root(a, w1, l1);
+            a.TW = TW;
+            p.tiles = (unsigned)(M * (cols >> a.log_c));
+            plan->passes.push_back(p);
+        }
+        {
+            PassPlan p;  // tile (k1, column group): over j at stride cols; output row k1 + N1 * k
+            p.log_t = l2;
+            NttPassArgs& a = p.args;
+            a.log_c = choose_log_c(l2, log_cols, target_threads);
+            const uint64_t C = (uint64_t)1 << a.log_c;
+            a.dsh = log_cols - a.log_c;
+            a.dmask = (uint32_t)((cols >> a.log_c) - 1);
+            a.inA = M * cols;
+            a.outA = cols;
+            a.inB = a.outB = C;
+            a.inC = a.outC = 1;
+            a.inS = cols;
+            a.outS = N1 * cols;
+            a.c_limit = ~0ull;
+            a.load_cfast = a.store_cfast = 1;
+            a.W = W2;
+            set_quarter_root(a, w2, l2);
+            p.tiles = (unsigned)(N1 * (cols >> a.log_c));
+            plan->passes.push_back(p);
+        }
+    }
+    *out = plan.get();
+    ctx->col_plans.push_back(std::move(plan));
+    return STARK_OK;
+}
+
+// d_in, d_out: [2^log_n][cols] elements; the whole matrix is one launch per pass (polynomials are in the tile grid)
+int run_col_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_out, hipStream_t stream) {
+    const uint64_t total = plan->cols << plan->log_n;
+    for (const PassPlan& p : plan->passes)
+        if ((uint64_t)p.tiles >= (1ull << 31)) return fail(ctx, STARK_ERR_UNSUPPORTED, "matrix too large for one launch");
+    uint32_t* tmp = nullptr;
+    if (plan->passes.size() > 1) {
+        int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, total * ntt29_mid_bytes());
+        if (rc != STARK_OK) return rc;
+        tmp = (uint32_t*)ctx->scratch;
+    }
+    for (size_t k = 0; k < plan->passes.size(); k++) {
+        const PassPlan& p = plan->passes[k];
+        NttPassArgs a = p.args;
+        a.in = k == 0 ? d_in : tmp;
+        a.out = k + 1 == plan->passes.size() ? d_out : tmp;
+        a.in_raw = k > 0;
+        a.out_raw = k + 1 < plan->passes.size();
+        a.ksh = 31;
+        a.kmask = 0xFFFFFFFFu;
+        HIP_TRY(ctx, launch_ntt29_pass(p.log_t, a, p.tiles, 1, stream));
+    }
+    return STARK_OK;
+}
+
+struct ShardGeom {
+    unsigned l1, l2;      // n = n1 * n2, n1 = 2^l1 (input index j = j1 + n1 * j2), n2 = 2^l2 (output index k = k1 * n2 + k2)
+    uint64_t n1, n2, r1, r2;  // r1 = n1 / world rows of stage A per rank, r2 = n2 / world columns of stage C per rank
+    unsigned log_r2;
+};
+
+// 0 = ok, else an error already recorded in the context
+int shard_geometry(stark_ctx* ctx, unsigned log_n, unsigned world, unsigned rank, ShardGeom& g) {
+    if (log_n > 30) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 30", log_n);
+    if (world == 0 || (world & (world - 1)) || rank >= world)
+        return fail(ctx, STARK_ERR_INVALID, "world %u must be a power of two and rank %u below it", world, rank);
+    g.l1 = log_n / 2;
+    g.l2 = log_n - g.l1;
+    g.n1 = (uint64_t)1 << g.l1;
+    g.n2 = (uint64_t)1 << g.l2;
+    if (g.n1 % world || g.n2 % world) return fail(ctx, STARK_ERR_INVALID, "world %u must divide n1 = 2^%u and n2 = 2^%u", world, g.l1, g.l2);
+    g.r1 = g.n1 / world;
+    g.r2 = g.n2 / world;
+    g.log_r2 = 0;
+    while (((uint64_t)1 << g.log_r2) < g.r2) g.log_r2++;
+    if (g.l1 < 2) return fail(ctx, STARK_ERR_UNSUPPORTED, "sharded transforms start at 2^4 points");
+    return STARK_OK;
+}
+
 }  // namespace
 
 // Nothing may unwind across the C ABI: every entry point is a function-try-block.
@@ -621,6 +825,111 @@ int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, si
     catch (...) { return STARK_ERR_HIP; }
 
 extern "C" {
+
+int stark_ntt_columns_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, size_t cols,
+                          const uint32_t root_of_unity[8], int inverse, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || (cols && (!d_in || !d_out))) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    if (log_n > 24) return fail(ctx, STARK_ERR_UNSUPPORTED, "log_n %u above 24", log_n);
+    if (log_n < 2) return fail(ctx, STARK_ERR_UNSUPPORTED, "column transforms start at 4 rows");
+    if (cols & (cols - 1)) return fail(ctx, STARK_ERR_UNSUPPORTED, "cols %zu is not a power of two", cols);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const U256 r = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(r, log_n)) return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    if (cols == 0) return STARK_OK;
+    NttPlan* plan = nullptr;
+    for (auto& p : ctx->col_plans)
+        if (p->log_n == log_n && p->cols == cols && p->inverse == (inverse != 0) && hostfe::eq(p->root, r)) plan = p.get();
+    if (!plan) {
+        int rc = build_col_plan(ctx, log_n, cols, r, inverse != 0, &plan);
+        if (rc != STARK_OK) return rc;
+    }
+    return run_col_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_out, stream ? (hipStream_t)stream : ctx->stream);
+} STARK_CATCH
+
+int stark_ntt_sharded_stage_a_dev(stark_ctx* ctx, const void* d_in, void* d_send, unsigned log_n, unsigned world,
+                                  unsigned rank, const uint32_t root_of_unity[8], int inverse, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || !d_in || !d_send || d_in == d_send) return fail(ctx, STARK_ERR_INVALID, "null or aliased buffers");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ShardGeom g;
+    int rc = shard_geometry(ctx, log_n, world, rank, g);
+    if (rc != STARK_OK) return rc;
+    const U256 w = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(w, log_n)) return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    // the n2-point row transforms: the ordinary plan of root^n1
+    const U256 wa = hostfe::pow_u64(w, g.n1);
+    NttPlan* plan;
+    if ((rc = get_plan(ctx, g.l2, wa, inverse != 0, &plan)) != STARK_OK) return rc;
+    if (plan->tiny) return fail(ctx, STARK_ERR_UNSUPPORTED, "sharded transforms start at 2^4 points");
+    // the last pass stores output index k1' + n1' * k; the send blocks split the index at r2, which must not cut k1'
+    if (plan->passes.size() > 1 && g.r2 < plan->passes.back().args.outS)
+        return fail(ctx, STARK_ERR_UNSUPPORTED, "world %u too large for a fused stage A at 2^%u points", world, log_n);
+    // twiddles w^(+-(rank * r1 + a) * k2) for this rank's rows, times n2^-1 when the plan is a single inverse pass
+    // (whose own scaling the table replaces)
+    NttPlan* tab = nullptr;
+    const uint64_t key = ((uint64_t)world << 32) | rank;
+    for (auto& p : ctx->stage_a_tabs)
+        if (p->log_n == log_n && p->cols == key && p->inverse == (inverse != 0) && hostfe::eq(p->root, w)) tab = p.get();
+    if (!tab) {
+        auto t = std::make_unique<NttPlan>();
+        t->log_n = log_n;
+        t->root = w;
+        t->inverse = inverse != 0;
+        t->cols = key;
+        const U256 base = inverse ? hostfe::pow_u64(w, ((uint64_t)1 << log_n) - 1) : w;
+        const U256 scale = (inverse && plan->passes.size() == 1) ? hostfe::inverse(hostfe::from_u64(g.n2)) : hostfe::from_u64(1);
+        uint32_t* tw;
+        if ((rc = make_table(ctx, t.get(), base, (size_t)(g.r1 * g.n2), g.n2, scale, &tw, false, (uint64_t)rank * g.r1)) != STARK_OK) {
+            free_plan(t.get());
+            return rc;
+        }
+        tab = t.get();
+        ctx->stage_a_tabs.push_back(std::move(t));
+    }
+    LastPassOverride ov;
+    ov.TW = (const uint32_t*)tab->tables[0];
+    ov.tw_poly = g.n2;
+    ov.out_poly = g.r2;               // row a of block d starts at d * r1 * r2 + a * r2
+    ov.ksh = g.log_r2;
+    ov.outS2 = g.r1 * g.r2;
+    return run_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_send, (size_t)g.r1, stream ? (hipStream_t)stream : ctx->stream,
+                    nullptr, 0, &ov);
+} STARK_CATCH
+
+int stark_ntt_sharded_stage_c_dev(stark_ctx* ctx, const void* d_recv, void* d_out, unsigned log_n, unsigned world,
+                                  const uint32_t root_of_unity[8], int inverse, void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (!root_of_unity || !d_recv || !d_out) return fail(ctx, STARK_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ShardGeom g;
+    int rc = shard_geometry(ctx, log_n, world, 0, g);
+    if (rc != STARK_OK) return rc;
+    const U256 w = hostfe::canon(hostfe::from_limbs(root_of_unity));
+    if (!has_order(w, log_n)) return fail(ctx, STARK_ERR_INVALID, "root of unity does not have order 2^%u", log_n);
+    uint32_t wc[8];
+    hostfe::to_limbs(hostfe::pow_u64(w, g.n2), wc);  // order n1
+    return stark_ntt_columns_dev(ctx, d_recv, d_out, g.l1, (size_t)g.r2, wc, inverse, stream);
+} STARK_CATCH
+
+int stark_ntt_sharded_dev(stark_ctx* ctx, void* d_x, void* d_y, unsigned log_n, unsigned world, unsigned rank,
+                          const uint32_t root_of_unity[8], int inverse, stark_all_to_all_fn exchange, void* user,
+                          void* stream) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (world > 1 && !exchange) return fail(ctx, STARK_ERR_INVALID, "an exchange function is required when world > 1");
+    void* st = stream ? stream : (void*)ctx->stream;
+    int rc = stark_ntt_sharded_stage_a_dev(ctx, d_x, d_y, log_n, world, rank, root_of_unity, inverse, st);
+    if (rc != STARK_OK) return rc;
+    const void* recv = d_y;  // one rank: the send blocks are the received ones
+    if (world > 1) {
+        const size_t block = (((size_t)1 << log_n) / world / world) * 32;
+        if (exchange(user, d_y, d_x, block, st) != 0) return fail(ctx, STARK_ERR_HIP, "the exchange function reported a failure");
+        recv = d_x;
+    }
+    // stage C is out of place: from the received blocks into the other buffer
+    return stark_ntt_sharded_stage_c_dev(ctx, recv, world > 1 ? d_y : d_x, log_n, world, root_of_unity, inverse, st);
+} STARK_CATCH
+
 
 int stark_version(void) { return 100; }
 
@@ -657,6 +966,8 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     for (auto& a : ctx->attach) a.reset();
     for (auto& p : ctx->plans) free_plan(p.get());
     for (auto& p : ctx->shard_tables) free_plan(p.get());
+    for (auto& p : ctx->col_plans) free_plan(p.get());
+    for (auto& p : ctx->stage_a_tabs) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
     for (int i = 0; i < 2; i++) {

@@ -40,8 +40,10 @@ hipError_t launch_merkle_verify(const uint8_t* values, const uint8_t* siblings, 
 //   tile index tau = blockIdx.x, hi = tau >> dsh, lo = tau & dmask, c in [0, 2^log_c)
 //   input  element j of tile (tau, c): in  + poly*poly_stride + hi*inA  + lo*inB  + c*inC  + j*inS
 //   output element k of tile (tau, c): out + poly*poly_stride + hi*outA + lo*outB + c*outC + k*outS
-//   if TW: output k is multiplied by TW[hi*twA + lo*twB + c*twC + k*twS] before the store
+//   if TW: output k is multiplied by TW[poly*twP + hi*twA + lo*twB + c*twC + k*twS] before the store
 //   tiles with lo*2^log_c + c >= c_limit are skipped (ragged batch in the single-pass case)
+//   the output's polynomial offset is poly*outP, and output k may be split in two: its k*outS term becomes
+//   (k >> ksh)*outS2 + (k & kmask)*outS (the send-block layout of a transform sharded over several GPUs)
 struct NttPassArgs {
     const uint32_t* in;
     uint32_t* out;
@@ -52,7 +54,10 @@ struct NttPassArgs {
     uint64_t poly_stride;
     uint64_t inA, inB, inC, inS;
     uint64_t outA, outB, outC, outS;
-    uint64_t twA, twB, twC, twS;
+    uint64_t twA, twB, twC, twS, twP;
+    uint64_t outP;   // polynomial stride of the output (the input's is poly_stride)
+    uint64_t outS2;  // see ksh
+    uint32_t ksh, kmask;  // 31 and 0xFFFFFFFF: no split
     uint64_t c_limit;
     uint32_t dsh, dmask;
     uint32_t log_c;
@@ -75,9 +80,9 @@ hipError_t launch_unpack_table(const uint32_t* in, uint32_t* out, size_t count, 
 // n = 1 or 2 (no radix-4 round exists): out = transform(in), one lane per polynomial
 hipError_t launch_ntt_tiny(const uint32_t* in, uint32_t* out, int log_n, size_t batch, const uint32_t scale[8],
                            int has_scale, hipStream_t stream);
-// out[i] = scale * base^e(i), e(i) = i (row_len == 0) or (i / row_len) * (i % row_len);
+// out[i] = scale * base^e(i), e(i) = i (row_len == 0) or (row0 + i / row_len) * (i % row_len);
 // pw[k] = base^(2^k), k < 64
-hipError_t launch_fill_powers(uint32_t* out, size_t count, uint64_t row_len, const uint32_t* pw_dev,
+hipError_t launch_fill_powers(uint32_t* out, size_t count, uint64_t row_len, uint64_t row0, const uint32_t* pw_dev,
                               const uint32_t scale[8], hipStream_t stream);
 // element-wise field op for tests: 0 add, 1 sub, 2 mul, 3 canon(a)
 hipError_t launch_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n, hipStream_t stream);

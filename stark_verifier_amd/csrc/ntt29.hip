@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             // the inter-pass twiddles of the first two outputs are requested before the last multiplication
             // of the butterfly, the other two one multiplication ahead of their use
             const bool tw_on = last && valid && a.TW != nullptr;
-            const uint32_t* tw = a.TW + 8 * (hi * a.twA + lo * a.twB + c * a.twC);
+            const uint32_t* tw = a.TW + 8 * (pidx * a.twP + hi * a.twA + lo * a.twB + c * a.twC);
             Fe t0, t1;
             if (tw_on) {
                 t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
@@ -357,18 +357,21 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 y2 = f29_mul(y2, sc);
                 y3 = f29_mul(y3, sc);
             }
-            uint32_t* dst = a.out + out_w * (poly + hi * a.outA + lo * a.outB + c * a.outC);
-            const uint64_t s = (uint64_t)out_w * a.outS;
+            uint32_t* dst = a.out + out_w * ((uint64_t)pidx * a.outP + hi * a.outA + lo * a.outB + c * a.outC);
+            // offset of output k (in dwords): k * outS, or split at bit ksh of k
+            auto ko = [&](uint32_t k) -> uint64_t {
+                return (uint64_t)out_w * ((uint64_t)(k >> a.ksh) * a.outS2 + (uint64_t)(k & a.kmask) * a.outS);
+            };
             if (a.out_raw) {
-                f29_store_mid(dst + s * j, y0);
-                f29_store_mid(dst + s * (j + Q), y1);
-                f29_store_mid(dst + s * (j + 2 * Q), y2);
-                f29_store_mid(dst + s * (j + 3 * Q), y3);
+                f29_store_mid(dst + ko(j), y0);
+                f29_store_mid(dst + ko(j + Q), y1);
+                f29_store_mid(dst + ko(j + 2 * Q), y2);
+                f29_store_mid(dst + ko(j + 3 * Q), y3);
             } else {
-                fe_store(dst + s * j, f29_to_fe(y0));
-                fe_store(dst + s * (j + Q), f29_to_fe(y1));
-                fe_store(dst + s * (j + 2 * Q), f29_to_fe(y2));
-                fe_store(dst + s * (j + 3 * Q), f29_to_fe(y3));
+                fe_store(dst + ko(j), f29_to_fe(y0));
+                fe_store(dst + ko(j + Q), f29_to_fe(y1));
+                fe_store(dst + ko(j + 2 * Q), f29_to_fe(y2));
+                fe_store(dst + ko(j + 3 * Q), f29_to_fe(y3));
             }
         }
         ns_log += 2;

@@ -47,11 +47,11 @@ struct ScaleArg {
     uint32_t l[8];
 };
 
-__global__ void fill_powers_kernel(uint32_t* __restrict__ out, size_t count, uint64_t row_len,
+__global__ void fill_powers_kernel(uint32_t* __restrict__ out, size_t count, uint64_t row_len, uint64_t row0,
                                    const uint32_t* __restrict__ pw, ScaleArg scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    uint64_t e = row_len ? (uint64_t)(i / row_len) * (uint64_t)(i % row_len) : (uint64_t)i;
+    uint64_t e = row_len ? (row0 + (uint64_t)(i / row_len)) * (uint64_t)(i % row_len) : (uint64_t)i;
     Fe acc;
 #pragma unroll
     for (int l = 0; l < 8; l++) acc.l[l] = scale.l[l];
@@ -61,13 +61,13 @@ __global__ void fill_powers_kernel(uint32_t* __restrict__ out, size_t count, uin
     fe_store(out + 8 * i, acc);
 }
 
-hipError_t launch_fill_powers(uint32_t* out, size_t count, uint64_t row_len, const uint32_t* pw_dev,
+hipError_t launch_fill_powers(uint32_t* out, size_t count, uint64_t row_len, uint64_t row0, const uint32_t* pw_dev,
                               const uint32_t scale[8], hipStream_t stream) {
     if (count == 0) return hipSuccess;
     ScaleArg s;
     for (int l = 0; l < 8; l++) s.l[l] = scale[l];
     hipLaunchKernelGGL(fill_powers_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, out, count,
-                       row_len, pw_dev, s);
+                       row_len, row0, pw_dev, s);
     return hipGetLastError();
 }
 

@@ -114,6 +114,26 @@ class HipLocalOps:
                                                        self._stream() or None))
         return out
 
+    def stage_a(self, t, log_n: int, world: int, rank: int, root: int, inverse: bool):
+        """Rows [r1][n2] -> send blocks [world][r1][r2]: row transforms, twiddles and packing in one pass sequence."""
+        import torch
+        from . import fft
+        out = torch.empty_like(t)
+        r = fft._limbs(root % fft.MODULUS)
+        self.ctx.check(self.ctx.lib.stark_ntt_sharded_stage_a_dev(self.ctx.handle, t.data_ptr(), out.data_ptr(), log_n, world,
+                                                                  rank, fft._ptr(r), int(bool(inverse)), self._stream() or None))
+        return out
+
+    def stage_c(self, t, log_n: int, world: int, root: int, inverse: bool):
+        """Received blocks [n1][r2] -> "columns" result [n1][r2]: column transforms where the data lies."""
+        import torch
+        from . import fft
+        out = torch.empty_like(t)
+        r = fft._limbs(root % fft.MODULUS)
+        self.ctx.check(self.ctx.lib.stark_ntt_sharded_stage_c_dev(self.ctx.handle, t.data_ptr(), out.data_ptr(), log_n, world,
+                                                                  fft._ptr(r), int(bool(inverse)), self._stream() or None))
+        return out
+
 
 def _all_to_all(t, group):
     """Equal-split all-to-all of a [world * m, 8] tensor along dim 0. Device tensors go through RCCL
@@ -148,7 +168,7 @@ def sharded_split(log_n: int):
 
 
 def ntt_sharded(x_local, log_n: int, root_of_unity: int, inverse: bool = False, group=None,
-                in_layout: str = "blocked", out_layout: str = "blocked", ops=None):
+                in_layout: str = "blocked", out_layout: str = "blocked", ops=None, fused=None):
     """One 2^log_n-point transform whose data is spread over the ranks of `group`.
 
     x_local: this rank's [n/world, 8] int32 tensor of limbs.
@@ -157,15 +177,22 @@ def ntt_sharded(x_local, log_n: int, root_of_unity: int, inverse: bool = False, 
     Returns this rank's [n/world, 8] tensor of the result X (fft_inv semantics if `inverse`):
       out_layout "blocked": X[rank*n/world : (rank+1)*n/world].
       out_layout "strided": row-major [n2/world][n1] with element (b, k1) = X[k1*n2 + rank*n2/world + b].
-    "strided" on both sides needs a single all-to-all; each "blocked" side adds one.
+      out_layout "columns": row-major [n1][n2/world] with element (k1, b) = X[k1*n2 + rank*n2/world + b]
+                            (the transpose of "strided"; what the fused path produces without a further step).
+    "strided" in and "strided" / "columns" out need a single all-to-all; each "blocked" side adds one.
     world must divide both n1 = 2^(log_n // 2) and n2 = n / n1. With no process group it runs the
     same steps on one rank.
+
+    fused (default: whenever `ops` offers stage_a / stage_c and the size allows): stage A multiplies by the twiddles
+    in its last pass's store and writes the send blocks directly, stage C transforms the received matrix's columns
+    where they lie (the library's stark_ntt_sharded_stage_{a,c}_dev). Otherwise the three-step form: row
+    transforms, stark_twiddle_mul_dev, pack / transpose kernels around the all-to-all, row transforms.
     """
     import contextlib
     import torch.distributed as dist
 
-    if in_layout not in ("blocked", "strided") or out_layout not in ("blocked", "strided"):
-        raise ValueError("layouts are 'blocked' or 'strided'")
+    if in_layout not in ("blocked", "strided") or out_layout not in ("blocked", "strided", "columns"):
+        raise ValueError("in_layout is 'blocked' or 'strided', out_layout 'blocked', 'strided' or 'columns'")
     ops = ops or HipLocalOps()
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
@@ -179,19 +206,41 @@ def ntt_sharded(x_local, log_n: int, root_of_unity: int, inverse: bool = False, 
     from .fft import MODULUS
     w = root_of_unity % MODULUS
     r1, r2 = n1 // world, n2 // world
+    if fused is None:
+        fused = hasattr(ops, "stage_a") and l1 >= 2 and world & (world - 1) == 0
 
     with getattr(ops, "stream_context", contextlib.nullcontext)():
         if in_layout == "blocked":
             # local slab [j2 in my range][j1] -> [j1 in my range][j2]
             s = _redistribute(x_local, r2, n1, world, group, ops)
         else:
-            s = x_local.clone()
-        ops.ntt_batch(s, l2, r1, pow(w, n1, MODULUS), inverse)                  # stage A over j2
-        ops.twiddle_mul(s, r1, n2, rank * r1, 0, log_n, w, inverse)             # w^(+-j1*k2)
-        u = _redistribute(s, r1, n2, world, group, ops)                         # [k2 in my range][j1]
-        ops.ntt_batch(u, l1, r2, pow(w, n2, MODULUS), inverse)                  # stage C over j1
-        if out_layout == "blocked":
-            u = _redistribute(u, r2, n1, world, group, ops)                     # [k1 in my range][k2]
+            s = x_local if fused else x_local.clone()
+        u = None
+        if fused:
+            try:
+                send = ops.stage_a(s, log_n, world, rank, w, inverse)               # [dest][j1 in my range][k2 in dest's]
+            except Exception as e:  # sizes the fused store does not take: the three-step form below
+                if getattr(e, "code", None) != -4:
+                    raise
+                fused = False
+                s = s.clone() if s is x_local else s
+            else:
+                got = _all_to_all(send, group)                                      # [n1][k2 in my range]
+                u = ops.stage_c(got, log_n, world, w, inverse)                      # "columns"
+                if out_layout == "strided":
+                    u = ops.permute3(u, n1, r2, 1)                                  # [k2 in my range][k1]
+                elif out_layout == "blocked":
+                    # rows k1 of rank d are the contiguous block d of the columns result: exchange, then interleave
+                    u = ops.permute3(_all_to_all(u, group), world, r1, r2) if world > 1 else u
+        if not fused:
+            ops.ntt_batch(s, l2, r1, pow(w, n1, MODULUS), inverse)                  # stage A over j2
+            ops.twiddle_mul(s, r1, n2, rank * r1, 0, log_n, w, inverse)             # w^(+-j1*k2)
+            u = _redistribute(s, r1, n2, world, group, ops)                         # [k2 in my range][j1]
+            ops.ntt_batch(u, l1, r2, pow(w, n2, MODULUS), inverse)                  # stage C over j1
+            if out_layout == "blocked":
+                u = _redistribute(u, r2, n1, world, group, ops)                     # [k1 in my range][k2]
+            elif out_layout == "columns":
+                u = ops.permute3(u, r2, n1, 1)
         if hasattr(u, "record_stream") and u.is_cuda:
             import torch
             u.record_stream(torch.cuda.current_stream())

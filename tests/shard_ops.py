@@ -31,3 +31,21 @@ class OracleLocalOps:
 
     def permute3(self, t, a, b, chunk):
         return t.reshape(a, b, chunk, 8).permute(1, 0, 2, 3).contiguous().reshape(-1, 8)
+
+    # the fused stages (the library's stark_ntt_sharded_stage_{a,c}_dev), from their definition
+    def stage_a(self, t, log_n, world, rank, root, inverse):
+        l1 = log_n // 2
+        n1, n2 = 1 << l1, 1 << (log_n - l1)
+        r1, r2 = n1 // world, n2 // world
+        s = t.clone()
+        self.ntt_batch(s, log_n - l1, r1, pow(root, n1, P), inverse)
+        self.twiddle_mul(s, r1, n2, rank * r1, 0, log_n, root, inverse)
+        return s.reshape(r1, world, r2, 8).permute(1, 0, 2, 3).contiguous().reshape(-1, 8)   # [dest][a][b]
+
+    def stage_c(self, t, log_n, world, root, inverse):
+        l1 = log_n // 2
+        n1, n2 = 1 << l1, 1 << (log_n - l1)
+        r2 = n2 // world
+        cols = t.reshape(n1, r2, 8).permute(1, 0, 2).contiguous().reshape(-1, 8)               # [b][j1]
+        self.ntt_batch(cols, l1, r2, pow(root, n2, P), inverse)
+        return cols.reshape(r2, n1, 8).permute(1, 0, 2).contiguous().reshape(-1, 8)            # [k1][b]

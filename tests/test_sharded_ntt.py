@@ -30,6 +30,8 @@ def _expected_slices(X, log_n, world, layout):
         return [X[r * n // world:(r + 1) * n // world] for r in range(world)]
     M = X.reshape(n1, n2, 8)  # X[k1*n2 + k2]
     r2 = n2 // world
+    if layout == "columns":
+        return [np.ascontiguousarray(M[:, r * r2:(r + 1) * r2]).reshape(-1, 8) for r in range(world)]
     return [np.ascontiguousarray(M[:, r * r2:(r + 1) * r2].transpose(1, 0, 2)).reshape(-1, 8) for r in range(world)]
 
 
@@ -53,10 +55,11 @@ def test_single_rank_all_layouts_cpu(log_n, inverse):
     x = synth.field_elements(77 + log_n, n)
     X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
     for li in ("blocked", "strided"):
-        for lo in ("blocked", "strided"):
-            xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy())
-            out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=OracleLocalOps())
-            assert np.array_equal(out.numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), (li, lo)
+        for lo in ("blocked", "strided", "columns"):
+            for fused in (True, False):
+                xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy())
+                out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=OracleLocalOps(), fused=fused)
+                assert np.array_equal(out.numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), (li, lo, fused)
 
 
 def test_rejects_bad_world_or_shape():
@@ -94,11 +97,48 @@ else:
 for inverse in (False, True):
     X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
     for li in ("blocked", "strided"):
-        for lo in ("blocked", "strided"):
-            xin = torch.from_numpy(_input_slices(x, log_n, world, li)[rank].view(np.int32).copy()).to(dev)
-            out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=ops)
-            got = out.cpu().numpy().view(np.uint32)
-            assert np.array_equal(got, _expected_slices(X, log_n, world, lo)[rank]), (rank, inverse, li, lo)
+        for lo in ("blocked", "strided", "columns"):
+            for fused in (True, False):
+                xin = torch.from_numpy(_input_slices(x, log_n, world, li)[rank].view(np.int32).copy()).to(dev)
+                out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, ops=ops, fused=fused)
+                got = out.cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, _expected_slices(X, log_n, world, lo)[rank]), (rank, inverse, li, lo, fused)
+if mode == "hip":
+    # the one-call C entry point with the exchange handed in as a callback (here: gloo, staged through host memory)
+    from stark_verifier_amd import _lib, fft
+    ctx = ops.ctx
+    def exchange(user, d_send, d_recv, block_bytes, stream):
+        try:
+            n_el = block_bytes * world // 32
+            assert stream == ctx.stream
+            # raw device pointers <-> torch tensors through the library's block copy (permute3 with a = b = 1)
+            send_t = torch.empty((n_el, 8), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            assert ctx.lib.stark_permute3_dev(ctx.handle, d_send, send_t.data_ptr(), 1, 1, n_el, None) == 0
+            ctx.synchronize()
+            src = send_t.cpu()
+            dst = torch.empty_like(src)
+            dist.all_to_all_single(dst, src)
+            back = dst.cuda()
+            torch.cuda.synchronize()
+            assert ctx.lib.stark_permute3_dev(ctx.handle, back.data_ptr(), d_recv, 1, 1, n_el, None) == 0
+            ctx.synchronize()
+            return 0
+        except Exception as e:   # never unwind into C
+            print("exchange failed:", repr(e), flush=True)
+            return 1
+    cb = _lib.ALL_TO_ALL_FN(exchange)
+    for inverse in (False, True):
+        X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+        xin = torch.from_numpy(_input_slices(x, log_n, world, "strided")[rank].view(np.int32).copy()).cuda()
+        y = torch.empty_like(xin)
+        torch.cuda.synchronize()
+        r = fft._limbs(w)
+        rc = ctx.lib.stark_ntt_sharded_dev(ctx.handle, xin.data_ptr(), y.data_ptr(), log_n, world, rank, fft._ptr(r),
+                                           int(inverse), cb, None, None)
+        assert rc == 0, ctx.lib.stark_last_error(ctx.handle)
+        ctx.synchronize()
+        assert np.array_equal(y.cpu().numpy().view(np.uint32), _expected_slices(X, log_n, world, "columns")[rank]), inverse
 dist.barrier()
 if rank == 0:
     print("ok")
@@ -139,10 +179,12 @@ def test_single_rank_hip_all_layouts(log_n):
     for inverse in (False, True):
         X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
         for li in ("blocked", "strided"):
-            for lo in ("blocked", "strided"):
-                xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy()).cuda()
-                out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo)
-                assert np.array_equal(out.cpu().numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), (inverse, li, lo)
+            for lo in ("blocked", "strided", "columns"):
+                for fused in (True, False):
+                    xin = torch.from_numpy(_input_slices(x, log_n, 1, li)[0].view(np.int32).copy()).cuda()
+                    out = ntt_sharded(xin, log_n, w, inverse, in_layout=li, out_layout=lo, fused=fused)
+                    assert np.array_equal(out.cpu().numpy().view(np.uint32), _expected_slices(X, log_n, 1, lo)[0]), \
+                        (inverse, li, lo, fused)
 
 
 @pytest.mark.gpu
@@ -231,3 +273,54 @@ def test_rccl_collectives_one_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     assert "ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_column_transforms_and_one_rank_stages_against_the_oracle():
+    """stark_ntt_columns_dev on [rows][cols] matrices (one pass up to 2^6 rows, two above; in and out of place) and the
+    fused stage A / stage C pair on one rank (stark_ntt_sharded_dev without an exchange), against the oracle's transform
+    of every column / of the whole vector."""
+    import stark_verifier_amd as sv
+    from stark_verifier_amd import _lib, fft
+    ctx = sv.default_context()
+    for log_rows, cols in ((2, 8), (5, 1), (6, 64), (7, 4), (10, 16), (12, 2), (9, 256)):
+        rows = 1 << log_rows
+        w = pow(7, (P - 1) >> log_rows, P)
+        x = synth.field_elements(500 + log_rows, rows * cols)
+        x[0] = 0xFFFFFFFF                       # a non-canonical input
+        M = x.reshape(rows, cols, 8)
+        for inverse in (False, True):
+            exp = np.empty_like(M)
+            for c in range(cols):
+                col = np.ascontiguousarray(M[:, c])
+                exp[:, c] = oracle.fft_inv(col, w) if inverse else oracle.fft_fwd(col, w)
+            t = torch.from_numpy(x.view(np.int32).copy()).cuda()
+            y = torch.empty_like(t)
+            torch.cuda.synchronize()
+            r = fft._limbs(w)
+            ctx.check(ctx.lib.stark_ntt_columns_dev(ctx.handle, t.data_ptr(), y.data_ptr(), log_rows, cols, fft._ptr(r), int(inverse), None))
+            ctx.check(ctx.lib.stark_ntt_columns_dev(ctx.handle, t.data_ptr(), t.data_ptr(), log_rows, cols, fft._ptr(r), int(inverse), None))
+            ctx.synchronize()
+            assert np.array_equal(y.cpu().numpy().view(np.uint32).reshape(rows, cols, 8), exp), (log_rows, cols, inverse)
+            assert torch.equal(t, y)
+    r = fft._limbs(pow(7, (P - 1) >> 10, P))
+    t = torch.zeros((1 << 10) * 3, 8, dtype=torch.int32).cuda()
+    assert ctx.lib.stark_ntt_columns_dev(ctx.handle, t.data_ptr(), t.data_ptr(), 10, 3, fft._ptr(r), 0, None) == _lib.STARK_ERR_UNSUPPORTED
+    assert ctx.lib.stark_ntt_columns_dev(ctx.handle, t.data_ptr(), t.data_ptr(), 9, 4, fft._ptr(r), 0, None) == _lib.STARK_ERR_INVALID
+    # one rank: rows in, columns out (= the natural order when world == 1), result left in the first buffer
+    for log_n in (4, 5, 11, 16, 18):
+        n = 1 << log_n
+        w = pow(7, (P - 1) >> log_n, P)
+        x = synth.field_elements(900 + log_n, n)
+        for inverse in (False, True):
+            X = oracle.fft_inv(x, w) if inverse else oracle.fft_fwd(x, w)
+            a = torch.from_numpy(_input_slices(x, log_n, 1, "strided")[0].view(np.int32).copy()).cuda()
+            b = torch.empty_like(a)
+            torch.cuda.synchronize()
+            r = fft._limbs(w)
+            ctx.check(ctx.lib.stark_ntt_sharded_dev(ctx.handle, a.data_ptr(), b.data_ptr(), log_n, 1, 0, fft._ptr(r), int(inverse),
+                                                    _lib.ALL_TO_ALL_FN(0), None, None))
+            ctx.synchronize()
+            assert np.array_equal(a.cpu().numpy().view(np.uint32), X), (log_n, inverse)
+    assert ctx.lib.stark_ntt_sharded_dev(ctx.handle, a.data_ptr(), b.data_ptr(), 18, 3, 0, fft._ptr(r), 0, _lib.ALL_TO_ALL_FN(0), None,
+                                         None) == _lib.STARK_ERR_INVALID

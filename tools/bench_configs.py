@@ -51,5 +51,21 @@ for name, log_n, B in (("cfg2_2^16_x1024", 16, 1024), ("metric_2^20_x32", 20, 32
         s1 = timed(lambda: ntt_sharded(x, log_n, w, False, ops=ops, in_layout="strided", out_layout="strided"), reps=3, warm=1)
         out[name]["sharded_path_one_rank_blocked_ms"] = s
         out[name]["sharded_path_one_rank_strided_ms"] = s1
+        out[name]["sharded_path_one_rank_rows_to_columns_ms"] = timed(
+            lambda: ntt_sharded(x, log_n, w, False, ops=ops, in_layout="strided", out_layout="columns"), reps=3, warm=1)
+        out[name]["sharded_three_step_one_rank_strided_ms"] = timed(
+            lambda: ntt_sharded(x, log_n, w, False, ops=ops, in_layout="strided", out_layout="strided", fused=False), reps=3, warm=1)
+        # the two stages alone through the C entry points (what a non-Python host calls around its exchange)
+        r = fft._limbs(w)
+        z = torch.empty_like(x)
+        out[name]["stage_a_ms"] = timed(lambda: ctx.check(ctx.lib.stark_ntt_sharded_stage_a_dev(
+            ctx.handle, x.data_ptr(), z.data_ptr(), log_n, 1, 0, fft._ptr(r), 0, None)), reps=5)
+        out[name]["stage_c_ms"] = timed(lambda: ctx.check(ctx.lib.stark_ntt_sharded_stage_c_dev(
+            ctx.handle, z.data_ptr(), y.data_ptr(), log_n, 1, fft._ptr(r), 0, None)), reps=5)
+        for world in (8,):
+            out[name]["stage_a_ms_rank0_of_%d" % world] = timed(lambda: ctx.check(ctx.lib.stark_ntt_sharded_stage_a_dev(
+                ctx.handle, x.data_ptr(), z.data_ptr(), log_n, world, 0, fft._ptr(r), 0, None)), reps=5)
+            out[name]["stage_c_ms_rank0_of_%d" % world] = timed(lambda: ctx.check(ctx.lib.stark_ntt_sharded_stage_c_dev(
+                ctx.handle, z.data_ptr(), y.data_ptr(), log_n, world, fft._ptr(r), 0, None)), reps=5)
     del x, y
 print(json.dumps(out, indent=1))
