@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--merkle-n", type=int, default=1 << 20, help="branches per step per GPU")
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--proofs", type=int, default=1250, help="MiMC STARK proofs per step per GPU (0 skips the region)")
+    ap.add_argument("--cfg2-batch", type=int, default=1024, help="polynomials of 2^16 points in the forward + inverse region (0 skips it)")
+    ap.add_argument("--sharded-log-n", type=int, default=24, help="size of the one transform sharded over the ranks (0 skips the region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -230,6 +232,111 @@ def main():
         ntt_step()
     torch.cuda.synchronize()
     dt_ntt, dev_ms_ntt = timed_region(ntt_step, args.steps, args.warmup, world, coll_device)
+
+    # ---- region A2: the inverse transform (fft_inv semantics) on the same shape ----
+    def inv_step():
+        sv.fft.ntt_batch_dev(y.data_ptr(), x.data_ptr(), log_n, B, root, True, ctx, stream)
+
+    for _ in range(2):
+        ntt_step()
+        inv_step()      # x = inverse(forward(x)) = x: the buffers keep their contents
+    torch.cuda.synchronize()
+    dt_inv, dev_ms_inv = timed_region(inv_step, args.steps, args.warmup, world, coll_device)
+
+    # ---- region A3 (BASELINE config 2): 1024 polynomials of 2^16 points, forward then inverse ----
+    cfg2 = None
+    if args.cfg2_batch > 0:
+        l2 = 16
+        n2_ = 1 << l2
+        B2 = max(1, min(args.cfg2_batch, (B * n) // n2_))     # what fits the resident buffers
+        root2 = pow(7, (P - 1) >> l2, P)
+        cx, cy = x[:B2 * n2_ * 8], y[:B2 * n2_ * 8]          # reuse the resident buffers (2 GiB = 1024 x 2 MiB)
+        ref2 = cx.clone()
+
+        def cfg2_fwd():
+            sv.fft.ntt_batch_dev(cx.data_ptr(), cy.data_ptr(), l2, B2, root2, False, ctx, stream)
+
+        def cfg2_inv():
+            sv.fft.ntt_batch_dev(cy.data_ptr(), cx.data_ptr(), l2, B2, root2, True, ctx, stream)
+
+        for _ in range(2):
+            cfg2_fwd()
+            cfg2_inv()
+        torch.cuda.synchronize()
+        cfg2_ok = bool(torch.equal(cx, ref2))
+        del ref2
+        dt2f, dev2f = timed_region(cfg2_fwd, args.steps, args.warmup, world, coll_device)
+        dt2i, dev2i = timed_region(cfg2_inv, args.steps, args.warmup, world, coll_device)
+        cfg2 = (l2, B2, dt2f, dev2f, dt2i, dev2i, cfg2_ok)
+        roundtrip_ok = roundtrip_ok and cfg2_ok
+
+    # ---- region A4 (BASELINE config 3): one 2^24-point transform sharded over the ranks, one all-to-all ----
+    sharded = None
+    if args.sharded_log_n > 0:
+        from stark_verifier_amd import sharding
+        ls = args.sharded_log_n
+        l1s = ls // 2
+        n1s, n2s, ns = 1 << l1s, 1 << (ls - l1s), 1 << ls
+        if n1s % world == 0 and n2s % world == 0 and ns * 8 <= x.numel():
+            roots = pow(7, (P - 1) >> ls, P)
+            full = x[:ns * 8].view(ns, 8)
+            ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, full.data_ptr(), ns, SEED + 3, stream))   # same vector on every rank
+            torch.cuda.synchronize()
+            r1s, r2s = n1s // world, n2s // world
+            # this rank's "rows" slice: element (a, j2) = x[(rank * r1 + a) + n1 * j2]
+            rows = full.view(n2s, n1s, 8)[:, rank * r1s:(rank + 1) * r1s].transpose(0, 1).contiguous().view(-1, 8)
+            single = y[:ns * 8].view(ns, 8)
+            sv.fft.ntt_batch_dev(full.data_ptr(), single.data_ptr(), ls, 1, roots, False, ctx, stream)
+            torch.cuda.synchronize()
+            expect_cols = single.view(n1s, n2s, 8)[:, rank * r2s:(rank + 1) * r2s].contiguous().view(-1, 8)
+            ops = sharding.HipLocalOps(ctx)
+            ops.tstream = torch.cuda.ExternalStream(stream, device=device)   # everything on this process's one stream
+            ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            phase_ms = [[], [], []]
+
+            def sharded_step():
+                ev3[0].record()
+                send = ops.stage_a(rows, ls, world, rank, roots, False)
+                ev3[1].record()
+                got = sharding._all_to_all(send, None)
+                ev3[2].record()
+                out = ops.stage_c(got, ls, world, roots, False)
+                ev3[3].record()
+                return out
+
+            def sharded_timed():
+                sharded_step()
+                ev3[3].synchronize()
+                for k in range(3):
+                    phase_ms[k].append(ev3[k].elapsed_time(ev3[k + 1]))
+
+            got_cols = sharded_step()
+            torch.cuda.synchronize()
+            sharded_ok = bool(torch.equal(got_cols, expect_cols))
+            # the other layouts through the library's orchestration: contiguous slices in and out (two more exchanges)
+            blocked_in = full[rank * (ns // world):(rank + 1) * (ns // world)]
+
+            def blocked_step():
+                return sharding.ntt_sharded(blocked_in, ls, roots, False, ops=ops)
+
+            got_blocked = blocked_step()
+            torch.cuda.synchronize()
+            sharded_ok = sharded_ok and bool(torch.equal(got_blocked, single[rank * (ns // world):(rank + 1) * (ns // world)]))
+            del got_cols, got_blocked
+            for _ in range(3):
+                sharded_step()
+            torch.cuda.synchronize()
+            phase_ms = [[], [], []]
+            dt_s, dev_ms_s = timed_region(sharded_timed, args.steps, min(args.warmup, 2), world, coll_device)
+            dt_sb, _ = timed_region(blocked_step, args.steps, min(args.warmup, 2), world, coll_device)
+
+            def single_step():
+                sv.fft.ntt_batch_dev(full.data_ptr(), single.data_ptr(), ls, 1, roots, False, ctx, stream)
+
+            dt_1, _ = timed_region(single_step, args.steps, min(args.warmup, 2), world, coll_device)
+            sharded = (ls, dt_s, dt_sb, dt_1, [float(np.mean(v)) if v else None for v in phase_ms], sharded_ok,
+                       (ns // world) * 32 * (world - 1) // world)
+            roundtrip_ok = roundtrip_ok and sharded_ok
 
     # ---- region B: depth-`depth` Merkle branch verification ----
     case = build_merkle_case(args.merkle_n, args.depth, SEED + 4 + rank)
@@ -313,7 +420,7 @@ def main():
             batch_res = {
                 "metric": "MiMC STARK proofs verified/sec (8192 steps, %d distinct synthetic proofs per GPU per step, 1 %% damaged)" % NP,
                 "value": world * NP * args.steps / dt_b, "unit": "proofs/s", "ms_per_step": dt_b / args.steps * 1e3,
-                "path": "host buffers in (structure check on host threads, upload, sampling + 1,240 branches + field checks per proof on the device), verdicts out",
+                "path": "host buffers in over PCIe (structure check on host threads, staged upload at the link's rate, sampling + 1,240 branches + field checks per proof on the device), verdicts out; device_resident_value is the same work with the proofs already in HBM",
                 "branches_per_s": 1240.0 * world * NP * args.steps / dt_b,
                 "device_resident_value": world * NP * args.steps / dt_r, "device_resident_ms_per_step": dt_r / args.steps * 1e3,
                 "proofs_made_on_device_per_s": NP / t_prove, "first_prover_call_s": t_prove_first,
@@ -382,6 +489,37 @@ def main():
                              "traffic": measured_traffic("merkle_verify_kernel<true>", args.merkle_n)},
             },
         }
+        inv_tops = ops_per_launch / (dev_ms_inv * 1e-3 / launches) * 1e-12
+        out["inverse"] = {
+            "metric": "256-bit inverse NTTs/sec at 2^%d points (fft_inv: inverse root and n^-1 scaling)" % log_n,
+            "value": world * B * K / dt_inv, "unit": "NTT/s", "ms_per_step": dt_inv / K * 1e3,
+            "launch_us": dev_ms_inv * 1e3 / launches, "launches_per_step": launches,
+            "roofline_frac": inv_tops / PEAK_VALU_TOPS,
+        }
+        if cfg2 is not None:
+            l2, B2, dt2f, dev2f, dt2i, dev2i, cfg2_ok = cfg2
+            bf2 = (1 << l2) // 2 * l2 * B2
+            out["cfg2"] = {
+                "workload": "%d polynomials of 2^%d points per GPU per step, forward and inverse timed separately" % (B2, l2),
+                "forward_value": world * B2 * K / dt2f, "inverse_value": world * B2 * K / dt2i, "unit": "NTT/s",
+                "forward_ms_per_step": dt2f / K * 1e3, "inverse_ms_per_step": dt2i / K * 1e3,
+                "forward_launch_us": dev2f * 1e3 / 2, "inverse_launch_us": dev2i * 1e3 / 2, "launches_per_step": 2,
+                "forward_roofline_frac": bf2 * OPS_PER_BUTTERFLY / (dev2f * 1e-3) * 1e-12 / PEAK_VALU_TOPS,
+                "inverse_roofline_frac": bf2 * OPS_PER_BUTTERFLY / (dev2i * 1e-3) * 1e-12 / PEAK_VALU_TOPS,
+                "inverse_of_forward_equals_input": cfg2_ok,
+            }
+        if sharded is not None:
+            ls, dt_s, dt_sb, dt_1, ph, sharded_ok, a2a_bytes = sharded
+            out["sharded_ntt"] = {
+                "workload": "one 2^%d-point forward transform spread over %d rank(s): rows in, columns out, one all-to-all" % (ls, world),
+                "value": K / dt_s, "unit": "transforms/s", "ms_per_step": dt_s / K * 1e3,
+                "stage_a_ms": ph[0], "all_to_all_ms": ph[1], "stage_c_ms": ph[2],
+                "all_to_all_bytes_sent_per_gpu": a2a_bytes,
+                "all_to_all_GBps_per_gpu": (a2a_bytes / (ph[1] * 1e-3) * 1e-9) if (ph[1] and a2a_bytes) else None,
+                "contiguous_in_and_out_ms_per_step": dt_sb / K * 1e3,
+                "single_gpu_call_ms_per_step": dt_1 / K * 1e3,
+                "equals_single_gpu_call": sharded_ok,
+            }
         if batch_res is not None:
             out["batch_verify"] = batch_res
             if "error" not in batch_res:

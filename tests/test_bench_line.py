@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--ntt-batch", "4",
-                        "--merkle-n", "8192", "--proofs", "6"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--merkle-n", "8192", "--proofs", "6", "--sharded-log-n", "22"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -33,3 +33,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cb["kind"] in ("port", "reference") and cb["cores"] == 1
     assert all(d["parity"].values())
     assert d["batch_verify"]["accept_vector_as_constructed"] is True and d["batch_verify"]["value"] > 0
+    # forward and inverse are reported separately, so are BASELINE's configurations 2 and 3
+    assert d["inverse"]["value"] > 0 and d["inverse"]["launch_us"] > 0
+    assert d["cfg2"]["forward_value"] > 0 and d["cfg2"]["inverse_value"] > 0 and d["cfg2"]["inverse_of_forward_equals_input"] is True
+    sh = d["sharded_ntt"]
+    assert sh["equals_single_gpu_call"] is True and sh["value"] > 0 and sh["all_to_all_bytes_sent_per_gpu"] == 0
+    for k in ("stage_a_ms", "all_to_all_ms", "stage_c_ms", "single_gpu_call_ms_per_step", "contiguous_in_and_out_ms_per_step"):
+        assert k in sh, k
