@@ -321,6 +321,15 @@ int stark_mimc_prove_batch_dev(stark_ctx* ctx, const void* d_inputs, size_t n, u
                                uint64_t proof_stride, void* d_outputs, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Encoding helpers (host only, no context): field elements in proofs and hashes are 32 big-endian bytes
+ * (BigInt::from_bytes_be at reference src/lib.rs:54,78,134-146,169-174; to_bytes_be on the prover's side), across
+ * this ABI they are 8 little-endian uint32 limbs. n elements each way; no reduction (a 32-byte value at or above p
+ * stays as it is: the transform entry points accept any 256-bit value). The buffers must not overlap.
+ * ------------------------------------------------------------------------------------- */
+void stark_be32_to_limbs(const uint8_t* be, size_t n, uint32_t* limbs);
+void stark_limbs_to_be32(const uint32_t* limbs, size_t n, uint8_t* be);
+
+/* ---------------------------------------------------------------------------------------
  * Test and benchmark support (no counterpart in the reference).
  * ------------------------------------------------------------------------------------- */
 

@@ -34,6 +34,7 @@ EXPORTS = [
     "stark_mimc_proof_size", "stark_mimc_prove_batch", "stark_mimc_prove_batch_dev", "stark_mimc_verify_batch_io", "stark_mimc_verify_batch_dev", "stark_mimc_batch", "stark_mimc_batch_dev",
     "stark_mimc_verify_batch_diag", "stark_ntt_batch_dev_static",
     "stark_ntt_sharded_stage_a_dev", "stark_ntt_sharded_stage_c_dev", "stark_ntt_sharded_dev", "stark_ntt_columns_dev",
+    "stark_be32_to_limbs", "stark_limbs_to_be32",
 ]
 
 
@@ -94,6 +95,10 @@ def load() -> ctypes.CDLL:
     L.stark_ntt_sharded_dev.restype = i32
     L.stark_ntt_columns_dev.argtypes = [vp, vp, vp, ctypes.c_uint, sz, vp, i32, vp]
     L.stark_ntt_columns_dev.restype = i32
+    L.stark_be32_to_limbs.argtypes = [vp, sz, vp]
+    L.stark_be32_to_limbs.restype = None
+    L.stark_limbs_to_be32.argtypes = [vp, sz, vp]
+    L.stark_limbs_to_be32.restype = None
     L.stark_merkle_verify_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, u32, vp, sz, vp, vp]
     L.stark_merkle_verify_batch.restype = i32
     L.stark_merkle_verify_batch_dev.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, vp, sz, vp, vp, vp]

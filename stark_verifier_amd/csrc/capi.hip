@@ -1225,6 +1225,27 @@ int stark_pseudorandom_indices(stark_ctx* ctx, const uint8_t* seeds, size_t n, u
     return STARK_OK;
 } STARK_CATCH
 
+// Pure host helpers: no context, no device.
+void stark_be32_to_limbs(const uint8_t* be, size_t n, uint32_t* limbs) {
+    for (size_t i = 0; i < n; i++)
+        for (int l = 0; l < 8; l++) {
+            const uint8_t* b = be + 32 * i + 4 * (7 - l);
+            limbs[8 * i + l] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        }
+}
+
+void stark_limbs_to_be32(const uint32_t* limbs, size_t n, uint8_t* be) {
+    for (size_t i = 0; i < n; i++)
+        for (int l = 0; l < 8; l++) {
+            const uint32_t v = limbs[8 * i + l];
+            uint8_t* b = be + 32 * i + 4 * (7 - l);
+            b[0] = (uint8_t)(v >> 24);
+            b[1] = (uint8_t)(v >> 16);
+            b[2] = (uint8_t)(v >> 8);
+            b[3] = (uint8_t)v;
+        }
+}
+
 int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* r, size_t n) try {
     if (!ctx) return STARK_ERR_INVALID;
     if (op < 0 || op > 7) return fail(ctx, STARK_ERR_INVALID, "unknown op %d", op);

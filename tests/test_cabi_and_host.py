@@ -34,6 +34,24 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) <= syms
 
 
+def test_big_endian_limb_helpers_round_trip():
+    """32 big-endian bytes (BigInt::from_bytes_be, reference src/lib.rs:54,169-174) <-> 8 little-endian u32 limbs:
+    host-only helpers, no context and no device needed."""
+    import numpy as np
+    from stark_verifier_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    vals = [0, 1, 2**256 - 1, 2**256 - 351 * 2**32 + 1, int.from_bytes(rng.bytes(32), "big"), 0x0102030405060708 << 130]
+    be = np.frombuffer(b"".join(v.to_bytes(32, "big") for v in vals), dtype=np.uint8).copy()
+    limbs = np.zeros(8 * len(vals), dtype=np.uint32)
+    lib.stark_be32_to_limbs(be.ctypes.data, len(vals), limbs.ctypes.data)
+    got = [int.from_bytes(limbs[8 * i:8 * i + 8].astype("<u4").tobytes(), "little") for i in range(len(vals))]
+    assert got == vals
+    back = np.zeros_like(be)
+    lib.stark_limbs_to_be32(limbs.ctypes.data, len(vals), back.ctypes.data)
+    assert np.array_equal(back, be)
+
+
 def test_context_creation_fails_loudly_without_gpu():
     import torch
     from stark_verifier_amd import _lib
