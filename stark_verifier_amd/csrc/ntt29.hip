@@ -28,6 +28,7 @@
 #include "field29.cuh"
 #include "internal.hpp"
 #include <stdlib.h>
+#include <atomic>
 
 namespace starkhip {
 
@@ -394,15 +395,17 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
     if (threads > 1024 || lds > 160 * 1024) return hipErrorInvalidConfiguration;
-    static bool attr_set[64] = {};  // per device: dynamic LDS above 64 KiB must be opted into
+    // per device: dynamic LDS above 64 KiB must be opted into. Contexts of several host threads may get here at once:
+    // the flags are atomic, and setting the attribute twice is harmless.
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 64 || !attr_set[dev]) {
+    if (dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass_kernel<LOGT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev < 64) attr_set[dev] = true;
+        if (dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     NttPassArgs b = a;
     static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 4;  // log2 of tiles per L2 group, -1 = off

@@ -115,3 +115,24 @@ def test_headline_shape_64_polys_of_2_20_against_the_oracle_in_full():
     fft.ntt_batch_dev(t.data_ptr(), t.data_ptr(), log_n, B, w, True, ctx)
     ctx.synchronize()
     assert torch.equal(t, z)
+
+
+@pytest.mark.parametrize("log_n", [15, 17, 18, 19, 21, 22, 23])
+def test_every_multi_pass_size_against_the_oracle_in_full(log_n):
+    """The sizes between the ones above: two passes with tiles of unequal or odd size (2^17 = 2^8 x 2^9, 2^19, 2^21),
+    three passes (2^22, 2^23). One polynomial each way, every element compared with the oracle's restatement of
+    fft.rs:37-86, plus the second polynomial of a batch of two (polynomial stride)."""
+    import stark_verifier_amd as sv
+    from stark_verifier_amd import fft
+    ctx = sv.default_context()
+    n = 1 << log_n
+    w = pow(7, (P - 1) >> log_n, P)
+    x = _fill(ctx, 2 * n, SEED + 40 + log_n)
+    y = torch.empty_like(x)
+    host = lambda t, b: t[b * n:(b + 1) * n].cpu().numpy().view(np.uint32)
+    fft.ntt_batch_dev(x.data_ptr(), y.data_ptr(), log_n, 2, w, False, ctx)
+    ctx.synchronize()
+    assert np.array_equal(host(y, 1), oracle.fft_fwd(host(x, 1), w))
+    fft.ntt_batch_dev(x.data_ptr(), y.data_ptr(), log_n, 2, w, True, ctx)
+    ctx.synchronize()
+    assert np.array_equal(host(y, 0), oracle.fft_inv(host(x, 0), w))
