@@ -841,6 +841,11 @@ int stark_ntt_columns_dev(stark_ctx* ctx, const void* d_in, void* d_out, unsigne
     for (auto& p : ctx->col_plans)
         if (p->log_n == log_n && p->cols == cols && p->inverse == (inverse != 0) && hostfe::eq(p->root, r)) plan = p.get();
     if (!plan) {
+        if (ctx->col_plans.size() >= 32) {  // tables of a column plan are small (the size of one column): a plain cap
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            free_plan(ctx->col_plans.front().get());
+            ctx->col_plans.erase(ctx->col_plans.begin());
+        }
         int rc = build_col_plan(ctx, log_n, cols, r, inverse != 0, &plan);
         if (rc != STARK_OK) return rc;
     }
@@ -885,6 +890,12 @@ int stark_ntt_sharded_stage_a_dev(stark_ctx* ctx, const void* d_in, void* d_send
             return rc;
         }
         tab = t.get();
+        // a table is as large as the rank's slice of the data: keep the four most recent ones
+        if (ctx->stage_a_tabs.size() >= 4) {
+            HIP_TRY(ctx, hipDeviceSynchronize());  // kernels in flight on any stream may still read the oldest
+            free_plan(ctx->stage_a_tabs.front().get());
+            ctx->stage_a_tabs.erase(ctx->stage_a_tabs.begin());
+        }
         ctx->stage_a_tabs.push_back(std::move(t));
     }
     LastPassOverride ov;
