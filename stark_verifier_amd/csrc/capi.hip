@@ -339,6 +339,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
     std::vector<int> split = choose_split(log_n);
     const int target_threads = env_int("STARKHIP_THREADS", 512);
     const int forced_log_c = env_int("STARKHIP_LOGC", -1);
+    const bool tiled_mid = env_int("STARKHIP_TILED_MID", 1) != 0;
     auto pick_c = [&](int log_t, unsigned log_extent) {
         int lc = choose_log_c(log_t, log_extent, log_t >= 12 ? 1024 : target_threads);
         if (forced_log_c >= 0 && forced_log_c <= (int)log_extent && (1 << (log_t - 2 + forced_log_c)) <= 1024 &&
@@ -403,6 +404,12 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             set_quarter_root(a, w1, l1);
             a.TW = TW1;
             p.tiles = (unsigned)(m >> a.log_c);
+            if (split.size() == 2 && tiled_mid) {
+                // two passes: the intermediate is stored tile by tile, [tile][k1][c] (n1 * C elements each), so that every
+                // workgroup writes one contiguous run of whole memory lines instead of n1 pieces of C * 36 bytes
+                a.outB = n1 * C;
+                a.outS = C;
+            }
             plan->passes.push_back(p);
         }
         if (split.size() == 2) {
@@ -431,6 +438,18 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             a.c_limit = ~0ull;
             a.load_cfast = 0;
             a.store_cfast = 1;
+            if (tiled_mid) {
+                // row k1 = lo * C + c of the tiled intermediate: element j is in tile j / C1 at [k1][j % C1]; the rows of
+                // one workgroup are adjacent there, so the lanes take the row index fastest
+                const uint32_t lc1 = plan->passes[0].args.log_c;
+                a.inB = C << lc1;
+                a.inC = (uint64_t)1 << lc1;
+                a.in_split = 1;
+                a.jsh = lc1;
+                a.jmask = (1u << lc1) - 1u;
+                a.inS2 = n1 << lc1;
+                a.load_cfast = 1;
+            }
             a.W = W2;
             set_quarter_root(a, w2, l2);
             p.tiles = (unsigned)(n1 >> a.log_c);

@@ -58,6 +58,10 @@ struct NttPassArgs {
     uint64_t outP;   // polynomial stride of the output (the input's is poly_stride)
     uint64_t outS2;  // see ksh
     uint32_t ksh, kmask;  // 31 and 0xFFFFFFFF: no split
+    // input element j of a tile sits at (j >> jsh) * inS2 + (j & jmask) * inS when in_split is set (the launcher
+    // fills jsh / jmask for "no split" otherwise): reads an intermediate that the previous pass stored tile by tile
+    uint32_t in_split, jsh, jmask;
+    uint64_t inS2;
     uint64_t c_limit;
     uint32_t dsh, dmask;
     uint32_t log_c;

@@ -206,17 +206,20 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         F29 x0, x1, x2, x3;
         if (valid) {
             const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
-            const uint64_t s = (uint64_t)in_w * a.inS;
+            // offset of input j (in dwords): j * inS, or split at bit jsh of j
+            auto jo = [&](uint32_t jj) -> uint64_t {
+                return (uint64_t)in_w * ((uint64_t)(jj >> a.jsh) * a.inS2 + (uint64_t)(jj & a.jmask) * a.inS);
+            };
             if (a.in_raw) {
-                x0 = f29_load_mid(src + s * j);
-                x1 = f29_load_mid(src + s * (j + Q));
-                x2 = f29_load_mid(src + s * (j + 2 * Q));
-                x3 = f29_load_mid(src + s * (j + 3 * Q));
+                x0 = f29_load_mid(src + jo(j));
+                x1 = f29_load_mid(src + jo(j + Q));
+                x2 = f29_load_mid(src + jo(j + 2 * Q));
+                x3 = f29_load_mid(src + jo(j + 3 * Q));
             } else {
-                x0 = f29_from_fe(fe_load(src + s * j));
-                x1 = f29_from_fe(fe_load(src + s * (j + Q)));
-                x2 = f29_from_fe(fe_load(src + s * (j + 2 * Q)));
-                x3 = f29_from_fe(fe_load(src + s * (j + 3 * Q)));
+                x0 = f29_from_fe(fe_load(src + jo(j)));
+                x1 = f29_from_fe(fe_load(src + jo(j + Q)));
+                x2 = f29_from_fe(fe_load(src + jo(j + 2 * Q)));
+                x3 = f29_from_fe(fe_load(src + jo(j + 3 * Q)));
             }
         } else {
 #pragma unroll
@@ -411,6 +414,10 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
     static const int grp = getenv("STARKHIP_GROUP") ? atoi(getenv("STARKHIP_GROUP")) : 4;  // log2 of tiles per L2 group, -1 = off
     b.tiles = tiles;
     b.polys = polys;
+    if (!b.in_split) {
+        b.jsh = 31;
+        b.jmask = 0xFFFFFFFFu;
+    }
     b.grp_log = 0;
     // the largest group up to 2^grp tiles that divides the tiles evenly over the 8 XCDs
     for (int g = grp; g >= 0; g--)
