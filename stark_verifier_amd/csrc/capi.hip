@@ -448,7 +448,7 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
                 a.jsh = lc1;
                 a.jmask = (1u << lc1) - 1u;
                 a.inS2 = n1 << lc1;
-                a.load_cfast = 1;
+                a.load_cfast = 1;  // element-fastest lanes (72-byte runs per wavefront) measured 1.5 % slower
             }
             a.W = W2;
             set_quarter_root(a, w2, l2);

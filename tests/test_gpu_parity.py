@@ -167,6 +167,33 @@ def test_ntt_large_sampled_and_roundtrip(sv, log_n, split, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("log_n,split,logc", [(13, None, None), (14, "4,10", None), (16, None, "0"), (17, "9,8", None), (20, None, None)])
+def test_ntt_two_pass_intermediate_layouts_agree(sv, log_n, split, logc, monkeypatch):
+    """Two-pass plans keep their intermediate tile by tile (default) or in place at the row stride
+    (STARKHIP_TILED_MID=0): same outputs, forward and inverse, and equal to the oracle where it is affordable."""
+    if split:
+        monkeypatch.setenv("STARKHIP_SPLIT", split)
+    if logc:
+        monkeypatch.setenv("STARKHIP_LOGC", logc)
+    n, batch = 1 << log_n, 3 if log_n <= 17 else 1
+    w = root_of_unity(log_n)
+    x = synth.field_elements(synth.SEED + 300 + log_n, batch * n).reshape(batch, n, 8)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STARKHIP_TILED_MID", mode)
+        ctx = sv.Context(0)  # the layout is chosen when a context builds the plan
+        fwd = sv.fft.ntt_batch(x, w, inverse=False, ctx=ctx)
+        inv = sv.fft.ntt_batch(x, w, inverse=True, ctx=ctx)
+        ctx.close()
+        outs.append((fwd, inv))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    if log_n <= 14:
+        for b in range(batch):
+            assert np.array_equal(outs[0][0][b], oracle.fft_fwd(x[b], w))
+            assert np.array_equal(outs[0][1][b], oracle.fft_inv(x[b], w))
+
+
 def test_ntt_linearity_2p20(sv):
     log_n, n = 20, 1 << 20
     w = root_of_unity(log_n)
