@@ -425,7 +425,7 @@ def main():
             batch_res = {
                 "metric": "MiMC STARK proofs verified/sec (8192 steps, %d distinct synthetic proofs per GPU per step, 1 %% damaged)" % NP,
                 "value": world * NP * args.steps / dt_b, "unit": "proofs/s", "ms_per_step": dt_b / args.steps * 1e3,
-                "path": "host buffers in over PCIe (structure check on host threads, staged upload at the link's rate, sampling + 1,240 branches + field checks per proof on the device), verdicts out; device_resident_value is the same work with the proofs already in HBM",
+                "path": "host buffers in over PCIe in 64 MiB pieces (structure check on host threads, staged upload at the link's rate and the kernels of the piece before overlap; sampling + 1,240 branches + field checks per proof on the device), verdicts out; device_resident_value is the same work with the proofs already in HBM",
                 "branches_per_s": 1240.0 * world * NP * args.steps / dt_b,
                 "device_resident_value": world * NP * args.steps / dt_r, "device_resident_ms_per_step": dt_r / args.steps * 1e3,
                 "proofs_made_on_device_per_s": NP / t_prove, "first_prover_call_s": t_prove_first,

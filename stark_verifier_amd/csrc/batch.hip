@@ -630,6 +630,9 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
     threads = std::max(1u, std::min(threads, 16u));
     size_t chunk_bytes = (size_t)1 << 30;
     if (const char* s = getenv("STARKHIP_BATCH_MB")) chunk_bytes = (size_t)atoi(s) << 20;
+    size_t piece_bytes = (size_t)64 << 20;  // upload granule of the pipelined fast path (one staging buffer)
+    if (const char* s = getenv("STARKHIP_PIECE_MB"))
+        if (atoi(s) > 0) piece_bytes = (size_t)atoi(s) << 20;
 
     // STARKHIP_BATCH_TIMING=1 prints per-stage wall time to stderr
     const bool timing = getenv("STARKHIP_BATCH_TIMING") != nullptr;
@@ -644,16 +647,83 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         while (c1 < n_proofs && c1 - c0 < 65535 && offsets[c1 + 1] - offsets[c0] <= chunk_bytes) c1++;
         const size_t m = c1 - c0;
         std::vector<ProofWork> work(m);
+        std::vector<uint8_t> fast_status(m, 0);
         double t0 = now();
+        const uint8_t* chunk_base = proofs + offsets[c0];
+        const size_t chunk_len = (size_t)(offsets[c1] - offsets[c0]);
         // proofs with the fixed instance's structure words are decided on the device without being parsed here
         std::vector<uint8_t> canon(m, 0);
-        if (use_fast)
-            parallel_for((m + 63) / 64, threads, [&](size_t blk) {
-                for (size_t i = blk * 64; i < std::min(m, blk * 64 + 64); i++) {
+        auto classify = [&](size_t i0, size_t i1) {
+            parallel_for((i1 - i0 + 15) / 16, threads, [&](size_t blk) {
+                for (size_t i = i0 + blk * 16; i < std::min(i1, i0 + blk * 16 + 16); i++) {
                     const uint64_t a = offsets[c0 + i], b = offsets[c0 + i + 1];
                     canon[i] = fast_is_canonical(proofs + a, (size_t)(b - a));
                 }
             });
+        };
+        // (input, slope) pairs of proofs who[k0 .. k1) into io
+        auto make_io = [&](const std::vector<size_t>& who, size_t k0, size_t k1, std::vector<uint32_t>& io) {
+            parallel_for((k1 - k0 + 255) / 256, threads, [&](size_t blk) {
+                for (size_t k = k0 + blk * 256; k < std::min(k1, k0 + blk * 256 + 256); k++) {
+                    const U256 in = P.inp(c0 + who[k]);
+                    hostfe::to_limbs(in, &io[16 * k]);
+                    hostfe::to_limbs(fe_mul(fe_sub(P.output(c0 + who[k]), in), P.inv_last_m1), &io[16 * k + 8]);
+                }
+            });
+        };
+        // the device reads 4-byte words: when every proof starts on a multiple of 4 inside the chunk, the chunk goes up in
+        // pieces of whole proofs and the structure check of a piece, the upload of the one before and the kernels of the
+        // one before that overlap
+        bool aligned = use_fast;
+        for (size_t i = c0; i < c1 && aligned; i++) aligned = (offsets[i] - offsets[c0]) % 4 == 0;
+        bool fast_done = false;
+        if (aligned) {
+            std::vector<size_t> cuts{0};       // piece boundaries (proof indices inside the chunk)
+            std::vector<size_t> byte_cuts{0};  // ... and as byte offsets
+            size_t max_piece = 0;
+            for (size_t i = 0; i < m;) {
+                size_t j = i + 1;
+                while (j < m && offsets[c0 + j + 1] - offsets[c0 + i] <= piece_bytes) j++;
+                max_piece = std::max(max_piece, j - i);
+                cuts.push_back(j);
+                byte_cuts.push_back((size_t)(offsets[c0 + j] - offsets[c0]));
+                i = j;
+            }
+            FastSession* ses = nullptr;
+            int rc = fast_session_begin(ctx, chunk_base, byte_cuts.data(), cuts.size() - 1, m, max_piece, &ses);
+            if (rc != STARK_OK) return rc;
+            std::vector<uint64_t> bases(m);
+            std::vector<size_t> who;
+            who.reserve(m);
+            std::vector<uint32_t> io(16 * m);
+            // the helper thread's staging copies use half of the host threads
+            const unsigned saved_threads = threads;
+            threads = std::max(1u, threads / 2);
+            for (size_t p = 0; p + 1 < cuts.size() && rc == STARK_OK; p++) {
+                const size_t i0 = cuts[p], i1 = cuts[p + 1], k0 = who.size();
+                double tc = now();
+                classify(i0, i1);
+                t_classify += now() - tc;
+                for (size_t i = i0; i < i1; i++)
+                    if (canon[i]) {
+                        bases[who.size()] = offsets[c0 + i] - offsets[c0];
+                        who.push_back(i);
+                    }
+                make_io(who, k0, who.size(), io);
+                rc = fast_session_piece(ctx, ses, bases.data() + k0, io.data() + 16 * k0, who.size() - k0, CP, d_mini);
+            }
+            threads = saved_threads;
+            std::vector<uint8_t> st(who.size());
+            const int rc_end = fast_session_end(ctx, ses, rc == STARK_OK ? st.data() : nullptr);
+            if (rc != STARK_OK) return rc;
+            if (rc_end != STARK_OK) return rc_end;
+            for (size_t k = 0; k < who.size(); k++) fast_status[who[k]] = st[k];
+            fast_done = true;
+            t_fast += now() - t0;
+            t0 = now();
+        } else if (use_fast) {
+            classify(0, m);
+        }
         t_classify += now() - t0;
         t0 = now();
         parallel_for(m, threads, [&](size_t i) {
@@ -701,8 +771,6 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         // In-place path: upload the chunk's proof bytes once and let every lane read its branch record where
         // it lies; needs every field at a multiple of 4 bytes. Otherwise (or with STARKHIP_BATCH_MERKLE=flatten)
         // the branches are copied into structure-of-arrays buffers on the host first.
-        const uint8_t* chunk_base = proofs + offsets[c0];
-        const size_t chunk_len = (size_t)(offsets[c1] - offsets[c0]);
         bool in_place = !force_flatten;
         for (size_t i = c0; i < c1 && in_place; i++) in_place = (offsets[i] - offsets[c0]) % 4 == 0;
         for (auto& kv : buckets) in_place = in_place && kv.second.vs % 4 == 0;
@@ -813,7 +881,10 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
         }
         t_field += now() - t0;
         t0 = now();
-        {
+        if (fast_done) {
+            for (size_t i = 0; i < m; i++)
+                if (canon[i]) work[i].status = fast_status[i];
+        } else {
             std::vector<uint64_t> bases;
             std::vector<size_t> who;
             for (size_t i = 0; i < m; i++)
@@ -821,30 +892,20 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
                     bases.push_back(offsets[c0 + i] - offsets[c0]);
                     who.push_back(i);
                 }
-            // the device reads 4-byte words: proofs that do not start on a multiple of 4 inside the chunk (a neighbour's
-            // length was odd) are copied, with the rest, into a packed buffer first
-            bool aligned = true;
-            for (uint64_t b : bases) aligned = aligned && b % 4 == 0;
+            // proofs that do not start on a multiple of 4 inside the chunk (a neighbour's length was odd) are copied, with
+            // the rest, into a packed buffer first
             const uint8_t* fast_chunk = chunk_base;
             size_t fast_len = chunk_len;
             std::vector<uint8_t> packed;
-            if (!who.empty() && !aligned) {
+            if (!who.empty()) {
                 const size_t psz = fast_proof_size();
                 packed.resize(psz * who.size());
                 parallel_for(who.size(), threads, [&](size_t k) { memcpy(&packed[psz * k], chunk_base + bases[k], psz); });
                 for (size_t k = 0; k < who.size(); k++) bases[k] = psz * k;
                 fast_chunk = packed.data();
                 fast_len = packed.size();
-            }
-            if (!who.empty()) {
                 std::vector<uint32_t> io(16 * who.size());
-                parallel_for((who.size() + 255) / 256, threads, [&](size_t blk) {
-                    for (size_t k = blk * 256; k < std::min(who.size(), blk * 256 + 256); k++) {
-                        const U256 in = P.inp(c0 + who[k]);
-                        hostfe::to_limbs(in, &io[16 * k]);
-                        hostfe::to_limbs(fe_mul(fe_sub(P.output(c0 + who[k]), in), P.inv_last_m1), &io[16 * k + 8]);
-                    }
-                });
+                make_io(who, 0, who.size(), io);
                 std::vector<uint8_t> st(who.size());
                 int rc = fast_verify(ctx, fast_chunk, fast_len, bases.data(), io.data(), who.size(), CP, d_mini, st.data());
                 if (rc != STARK_OK) {

@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/starkhip.h"
@@ -161,16 +163,26 @@ struct DevTemplate : CtxAttachment {
     TCon* con = nullptr;
     TWord* words = nullptr;
     uint32_t n_words = 0;
-    // grow-only device buffers kept across calls: [0] descriptors, lanes and verdicts; [1] an uploaded chunk
-    uint8_t* buf[2] = {nullptr, nullptr};
-    size_t buf_bytes[2] = {0, 0};
+    // grow-only device buffers kept across calls: [0] descriptors, lanes and partial verdicts; [1] an uploaded chunk
+    // with its per-proof offsets, inputs and verdicts; [2] verdicts of resident proofs
+    uint8_t* buf[3] = {nullptr, nullptr, nullptr};
+    size_t buf_bytes[3] = {0, 0, 0};
+    // pipelined host path: kernels of piece k run on `compute` while piece k + 1 is on the link (the context's stream);
+    // `pinned` carries the per-proof offsets and inputs up and the verdicts down without a blocking pageable copy
+    hipStream_t compute = nullptr;
+    uint8_t* pinned = nullptr;
+    size_t pinned_bytes = 0;
     ~DevTemplate() override {
+        if (compute) {
+            (void)hipStreamSynchronize(compute);
+            (void)hipStreamDestroy(compute);
+        }
+        if (pinned) (void)hipHostFree(pinned);
         (void)hipFree(branches);
         (void)hipFree(fri);
         (void)hipFree(con);
         (void)hipFree(words);
-        (void)hipFree(buf[0]);
-        (void)hipFree(buf[1]);
+        for (uint8_t* b : buf) (void)hipFree(b);
     }
 };
 constexpr int FAST_SLOT = 1;
@@ -405,6 +417,7 @@ static int get_dev_template(stark_ctx* ctx, DevTemplate** out) {
 static int kept_buffer(stark_ctx* ctx, DevTemplate* D, int which, size_t need, uint8_t** out) {
     if (D->buf_bytes[which] < need) {
         F_TRY(hipStreamSynchronize((hipStream_t)stark_ctx_stream(ctx)));
+        if (D->compute) F_TRY(hipStreamSynchronize(D->compute));
         if (D->buf[which]) F_TRY(hipFree(D->buf[which]));
         D->buf[which] = nullptr;
         D->buf_bytes[which] = 0;
@@ -417,29 +430,45 @@ static int kept_buffer(stark_ctx* ctx, DevTemplate* D, int which, size_t need, u
 
 // Everything resident: d_blob holds the proofs, d_base[i] the offset of canonical proof i inside it (a multiple of 4),
 // d_io per proof 8 + 8 canonical limbs (input, slope). status_out (host) as the general path would set it.
-int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io, size_t mc,
-                         const CheckParams& CP, const uint32_t* d_mini, uint8_t* status_out) {
-    if (mc == 0) return STARK_OK;
-    const Template& T = tmpl();
-    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
-    DevTemplate* D;
-    int rc = get_dev_template(ctx, &D);
-    if (rc != STARK_OK) return rc;
-    const uint32_t m = (uint32_t)mc;
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+// where the descriptors, lanes and partial verdicts of m proofs sit inside kept buffer 0
+struct LaneLayout {
+    size_t o_samp, o_rec, o_root, o_idx, o_acc, o_fri, o_con, o_kk, o_chk, total;
+};
+static LaneLayout lane_layout(size_t m) {
+    LaneLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) {
         const size_t at = o;
-        o += up(bytes);
+        o += (bytes + 255) & ~(size_t)255;
         return at;
     };
     const size_t nb = (size_t)N_BRANCH * m;
-    const size_t o_samp = take(4 * (size_t)N_SAMPLES * m), o_rec = take(8 * nb), o_root = take(8 * nb), o_idx = take(4 * nb),
-                 o_acc = take(nb), o_fri = take(sizeof(FriLane) * (size_t)N_FRI * m),
-                 o_con = take(sizeof(ConstraintLane) * (size_t)SPOT * m), o_kk = take(CHECK_PROOF_BYTES * (size_t)m),
-                 o_chk = take((size_t)(N_FRI + SPOT) * m), o_st = take(m);
+    L.o_samp = take(4 * (size_t)N_SAMPLES * m);
+    L.o_rec = take(8 * nb);
+    L.o_root = take(8 * nb);
+    L.o_idx = take(4 * nb);
+    L.o_acc = take(nb);
+    L.o_fri = take(sizeof(FriLane) * (size_t)N_FRI * m);
+    L.o_con = take(sizeof(ConstraintLane) * (size_t)SPOT * m);
+    L.o_kk = take(CHECK_PROOF_BYTES * (size_t)m);
+    L.o_chk = take((size_t)(N_FRI + SPOT) * m);
+    L.total = o;
+    return L;
+}
+static size_t fast_lane_bytes(size_t m) { return lane_layout(m).total; }
+
+// The launches alone, on stream `st`: one verdict byte per proof to d_status (device memory). The lanes and descriptors
+// live in kept buffer 0, which consecutive calls on one stream may share.
+static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io,
+                       size_t mc, const CheckParams& CP, const uint32_t* d_mini, hipStream_t st, uint8_t* d_status) {
+    const Template& T = tmpl();
+    int rc;
+    const uint32_t m = (uint32_t)mc;
+    const LaneLayout L = lane_layout(m);
+    const size_t o_samp = L.o_samp, o_rec = L.o_rec, o_root = L.o_root, o_idx = L.o_idx, o_acc = L.o_acc, o_fri = L.o_fri,
+                 o_con = L.o_con, o_kk = L.o_kk, o_chk = L.o_chk;
     uint8_t* d = nullptr;
-    if ((rc = kept_buffer(ctx, D, 0, o, &d)) != STARK_OK) return rc;
+    if ((rc = kept_buffer(ctx, D, 0, L.total, &d)) != STARK_OK) return rc;
     uint32_t* samples = (uint32_t*)(d + o_samp);
     SeedOffs so;
     memcpy(so.off, T.seed_off, sizeof so.off);
@@ -467,10 +496,144 @@ int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* 
     F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, st));
     F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
                                   d + o_chk + (size_t)N_FRI * m, st));
-    hipLaunchKernelGGL(vstatus_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d + o_st);
+    hipLaunchKernelGGL(vstatus_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
     F_TRY(hipGetLastError());
-    F_TRY(hipMemcpyAsync(status_out, d + o_st, m, hipMemcpyDeviceToHost, st));
+    return STARK_OK;
+}
+
+int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io, size_t mc,
+                         const CheckParams& CP, const uint32_t* d_mini, uint8_t* status_out) {
+    if (mc == 0) return STARK_OK;
+    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+    DevTemplate* D;
+    int rc = get_dev_template(ctx, &D);
+    if (rc != STARK_OK) return rc;
+    uint8_t* d_status = nullptr;
+    if ((rc = kept_buffer(ctx, D, 2, (mc + 255) & ~(size_t)255, &d_status)) != STARK_OK) return rc;
+    if ((rc = fast_launch(ctx, D, d_blob, d_base, d_io, mc, CP, d_mini, st, d_status)) != STARK_OK) return rc;
+    F_TRY(hipMemcpyAsync(status_out, d_status, mc, hipMemcpyDeviceToHost, st));
     F_TRY(hipStreamSynchronize(st));
+    return STARK_OK;
+}
+
+// ---- pipelined host path --------------------------------------------------------------------------------------
+// A chunk of proofs in host memory goes up in pieces of whole proofs. A helper thread does nothing but stage and
+// queue the pieces on the context's stream, back to back (the upload needs nothing from the structure check);
+// the calling thread meanwhile classifies piece after piece and queues each piece's kernels on a second stream
+// behind that piece's upload event, so the link never waits for the host's checks or for the kernels.
+// begin: buffers for the whole chunk, start the uploads (cuts[p] .. cuts[p + 1] = byte range of piece p);
+// piece: queue the checks of the `count` canonical proofs of the next piece (bases: their offsets inside the chunk,
+// io: 16 limbs each); end: wait and hand the verdicts back in the order the proofs were given.
+struct FastSession {
+    DevTemplate* D = nullptr;
+    uint8_t* d = nullptr;  // kept buffer 1: chunk bytes, then offsets, inputs and verdicts of every proof
+    size_t o_base = 0, o_io = 0, o_st = 0, cap = 0, done = 0, next_piece = 0;
+    std::vector<hipEvent_t> events;       // events[p]: piece p is on the device
+    std::vector<size_t> cuts;
+    std::atomic<size_t> queued{0};        // pieces whose upload has been queued (and its event recorded)
+    std::atomic<int> upload_error{0};     // hipError_t of the helper thread
+    std::thread uploader;
+};
+
+int fast_session_begin(stark_ctx* ctx, const uint8_t* chunk, const size_t* cuts, size_t n_pieces, size_t max_proofs,
+                       size_t max_piece_proofs, FastSession** out) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    std::unique_ptr<FastSession> S(new FastSession);
+    int rc = get_dev_template(ctx, &S->D);
+    if (rc != STARK_OK) return rc;
+    DevTemplate* D = S->D;
+    if (!D->compute) F_TRY(hipStreamCreateWithFlags(&D->compute, hipStreamNonBlocking));
+    const size_t pin_need = up(8 * max_proofs) + up(64 * max_proofs) + up(max_proofs);
+    if (D->pinned_bytes < pin_need) {
+        F_TRY(hipStreamSynchronize((hipStream_t)stark_ctx_stream(ctx)));
+        F_TRY(hipStreamSynchronize(D->compute));
+        if (D->pinned) F_TRY(hipHostFree(D->pinned));
+        D->pinned = nullptr;
+        D->pinned_bytes = 0;
+        F_TRY(hipHostMalloc((void**)&D->pinned, pin_need, hipHostMallocDefault));
+        D->pinned_bytes = pin_need;
+    }
+    const size_t chunk_len = cuts[n_pieces];
+    S->o_base = up(chunk_len + 16);
+    S->o_io = S->o_base + up(8 * max_proofs);
+    S->o_st = S->o_io + up(64 * max_proofs);
+    S->cap = max_proofs;
+    S->cuts.assign(cuts, cuts + n_pieces + 1);
+    if ((rc = kept_buffer(ctx, D, 1, S->o_st + up(max_proofs), &S->d)) != STARK_OK) return rc;
+    // size the lane buffer for the largest piece now: growing it later would free memory that queued kernels use
+    uint8_t* lanes;
+    if ((rc = kept_buffer(ctx, D, 0, fast_lane_bytes(max_piece_proofs), &lanes)) != STARK_OK) return rc;
+    S->events.resize(n_pieces, nullptr);
+    for (size_t p = 0; p < n_pieces; p++) {
+        hipError_t e = hipEventCreateWithFlags(&S->events[p], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (size_t q = 0; q < p; q++) (void)hipEventDestroy(S->events[q]);
+            F_TRY(e);
+        }
+    }
+    FastSession* s = S.get();
+    s->uploader = std::thread([ctx, s, chunk] {
+        hipStream_t link = (hipStream_t)stark_ctx_stream(ctx);
+        hipError_t e = ctx_make_current(ctx);  // the current device is per thread
+        for (size_t p = 0; p + 1 < s->cuts.size(); p++) {
+            const size_t lo = s->cuts[p], hi = s->cuts[p + 1];
+            if (e == hipSuccess && hi > lo) e = copy_h2d(ctx, s->d + lo, chunk + lo, hi - lo, link);
+            if (e == hipSuccess) e = hipEventRecord(s->events[p], link);
+            if (e != hipSuccess) s->upload_error.store((int)e);
+            s->queued.store(p + 1, std::memory_order_release);  // also after an error: nobody may wait for ever
+        }
+    });
+    *out = S.release();
+    return STARK_OK;
+}
+
+int fast_session_piece(stark_ctx* ctx, FastSession* S, const uint64_t* bases, const uint32_t* io, size_t count,
+                       const CheckParams& CP, const uint32_t* d_mini) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    DevTemplate* D = S->D;
+    const size_t p = S->next_piece++;
+    if (p + 1 >= S->cuts.size() || S->done + count > S->cap) return STARK_ERR_INVALID;
+    if (count == 0) return STARK_OK;
+    uint8_t* pin_base = D->pinned + 8 * S->done;
+    uint8_t* pin_io = D->pinned + up(8 * S->cap) + 64 * S->done;
+    memcpy(pin_base, bases, 8 * count);
+    memcpy(pin_io, io, 64 * count);
+    F_TRY(hipMemcpyAsync(S->d + S->o_base + 8 * S->done, pin_base, 8 * count, hipMemcpyHostToDevice, D->compute));
+    F_TRY(hipMemcpyAsync(S->d + S->o_io + 64 * S->done, pin_io, 64 * count, hipMemcpyHostToDevice, D->compute));
+    while (S->queued.load(std::memory_order_acquire) <= p) std::this_thread::yield();
+    if (S->upload_error.load()) {
+        ctx_set_error(ctx, "staged upload of a piece of the chunk failed");
+        return STARK_ERR_HIP;
+    }
+    F_TRY(hipStreamWaitEvent(D->compute, S->events[p], 0));
+    int rc = fast_launch(ctx, D, S->d, (const uint64_t*)(S->d + S->o_base) + S->done, (const uint32_t*)(S->d + S->o_io) + 16 * S->done,
+                         count, CP, d_mini, D->compute, S->d + S->o_st + S->done);
+    if (rc != STARK_OK) return rc;
+    S->done += count;
+    return STARK_OK;
+}
+
+// Also the way out after an error: waits for the uploads and for everything queued, then releases the session.
+// status_out may be null then.
+int fast_session_end(stark_ctx* ctx, FastSession* S, uint8_t* status_out) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    std::unique_ptr<FastSession> guard(S);
+    DevTemplate* D = S->D;
+    if (S->uploader.joinable()) S->uploader.join();
+    hipError_t e = (hipError_t)S->upload_error.load();
+    if (e == hipSuccess && status_out && S->done) {
+        uint8_t* pin_st = D->pinned + up(8 * S->cap) + up(64 * S->cap);
+        e = hipMemcpyAsync(pin_st, S->d + S->o_st, S->done, hipMemcpyDeviceToHost, D->compute);
+        if (e == hipSuccess) e = hipStreamSynchronize(D->compute);
+        if (e == hipSuccess) memcpy(status_out, pin_st, S->done);
+    } else {
+        hipError_t e1 = hipStreamSynchronize(D->compute);
+        if (e == hipSuccess) e = e1;
+    }
+    hipError_t e2 = hipStreamSynchronize((hipStream_t)stark_ctx_stream(ctx));
+    for (hipEvent_t ev : S->events) (void)hipEventDestroy(ev);
+    F_TRY(e);
+    F_TRY(e2);
     return STARK_OK;
 }
 

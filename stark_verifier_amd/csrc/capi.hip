@@ -70,6 +70,8 @@ struct stark_ctx {
     // pinned staging for copies from / to pageable host memory
     char* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};  // a transfer recorded in pin_ev[i] may still read or write pin[i]
+    unsigned pin_next = 0;              // the buffer the next staged piece takes (they alternate across calls too)
     bool pin_tried = false;
     unsigned copy_threads = 8;
 };
@@ -120,25 +122,33 @@ void par_copy(char* dst, const char* src, size_t n, unsigned threads) {
 }
 }  // namespace
 
+// Before pin[b] is written again: wait for the transfer that last used it. Waiting here, not at the end of the call
+// that started the transfer, lets the caller prepare its next piece while the last one is still on the link.
+static hipError_t pin_acquire(stark_ctx* ctx, unsigned b) {
+    if (!ctx->pin_busy[b]) return hipSuccess;
+    ctx->pin_busy[b] = false;
+    return hipEventSynchronize(ctx->pin_ev[b]);
+}
+
+// Pageable host memory -> device through the two pinned buffers. On return `src` has been read completely; the last one
+// or two pieces may still be in flight on `stream`.
 hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t stream) {
     if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
     hipError_t e = hipSuccess;
-    size_t k = 0;
-    for (size_t o = 0; o < n && e == hipSuccess; o += PIN_BYTES, k++) {
+    for (size_t o = 0; o < n && e == hipSuccess; o += PIN_BYTES) {
         const size_t len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-        char* buf = ctx->pin[k & 1];
-        if (k >= 2) e = hipEventSynchronize(ctx->pin_ev[k & 1]);  // the transfer that last used this buffer
-        if (e != hipSuccess) break;
-        par_copy(buf, (const char*)src + o, len, ctx->copy_threads);
-        e = hipMemcpyAsync((char*)d_dst + o, buf, len, hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[k & 1], stream);
+        const unsigned b = ctx->pin_next;
+        ctx->pin_next ^= 1u;
+        if ((e = pin_acquire(ctx, b)) != hipSuccess) break;
+        par_copy(ctx->pin[b], (const char*)src + o, len, ctx->copy_threads);
+        e = hipMemcpyAsync((char*)d_dst + o, ctx->pin[b], len, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[b], stream);
+        if (e == hipSuccess) ctx->pin_busy[b] = true;
     }
-    // the buffers are reused by the next call: wait for the transfers that still read them
-    for (int i = 0; i < 2 && e == hipSuccess; i++)
-        if (k > (size_t)i) e = hipEventSynchronize(ctx->pin_ev[i]);
     return e;
 }
 
+// Device -> pageable host memory; complete on return.
 hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipStream_t stream) {
     if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) {
         hipError_t e = hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream);
@@ -146,18 +156,24 @@ hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipS
     }
     hipError_t e = hipSuccess;
     const size_t chunks = (n + PIN_BYTES - 1) / PIN_BYTES;
+    const unsigned first = ctx->pin_next;
     for (size_t k = 0; k <= chunks && e == hipSuccess; k++) {
         if (k < chunks) {
             const size_t o = k * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-            e = hipMemcpyAsync(ctx->pin[k & 1], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[k & 1], stream);
+            const unsigned b = (first + (unsigned)k) & 1u;
+            e = pin_acquire(ctx, b);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->pin[b], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[b], stream);
+            if (e == hipSuccess) ctx->pin_busy[b] = true;
         }
         if (k >= 1 && e == hipSuccess) {
             const size_t o = (k - 1) * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-            e = hipEventSynchronize(ctx->pin_ev[(k - 1) & 1]);
-            if (e == hipSuccess) par_copy((char*)dst + o, ctx->pin[(k - 1) & 1], len, ctx->copy_threads);
+            const unsigned b = (first + (unsigned)(k - 1)) & 1u;
+            e = pin_acquire(ctx, b);
+            if (e == hipSuccess) par_copy((char*)dst + o, ctx->pin[b], len, ctx->copy_threads);
         }
     }
+    ctx->pin_next = (first + (unsigned)chunks) & 1u;
     return e;
 }
 
@@ -1001,6 +1017,7 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
     for (int i = 0; i < 2; i++) {
+        if (ctx->pin_busy[i]) (void)hipEventSynchronize(ctx->pin_ev[i]);  // a transfer on a caller's stream
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }

@@ -143,6 +143,20 @@ int fast_verify(stark_ctx* ctx, const uint8_t* chunk, size_t chunk_len, const ui
 // the same with the proofs, offsets and (input, slope) pairs already in device memory
 int fast_verify_resident(stark_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io, size_t mc,
                          const CheckParams& CP, const uint32_t* d_mini, uint8_t* status_out);
+// The same for a chunk in host memory taken in pieces of whole proofs (cuts[p] .. cuts[p + 1] = byte range of piece p,
+// n_pieces + 1 entries): a helper thread stages and queues the pieces back to back on the context's stream while the
+// caller prepares piece after piece and queues its kernels on a second stream, so the upload, the kernels and the
+// host's structure check overlap. begin: device buffers for the chunk and at most max_proofs canonical proofs
+// (max_piece_proofs in any one piece), uploads started; piece: queue the checks of the `count` canonical proofs of
+// the next piece, one call per piece in order (bases = offsets inside the chunk, io as above); end: wait, verdicts in
+// the order the proofs were queued. end must be called after begin succeeded, also after a failed piece (status_out
+// may then be null). The context must not be used by anything else between begin and end.
+struct FastSession;
+int fast_session_begin(stark_ctx* ctx, const uint8_t* chunk, const size_t* cuts, size_t n_pieces, size_t max_proofs,
+                       size_t max_piece_proofs, FastSession** out);
+int fast_session_piece(stark_ctx* ctx, FastSession* s, const uint64_t* bases, const uint32_t* io, size_t count,
+                       const CheckParams& CP, const uint32_t* d_mini);
+int fast_session_end(stark_ctx* ctx, FastSession* s, uint8_t* status_out);
 // structure check of device-resident proofs at d_proofs + i * stride; canonical_out is a host array
 int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t n, uint8_t* canonical_out);
 // d_io[k] = (canonical input, slope) of proof d_who[k] from device-resident n x 8-limb inputs / outputs
