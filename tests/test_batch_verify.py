@@ -113,6 +113,29 @@ def test_batch_chunking_and_threads_give_the_same_answer(proof_bytes, monkeypatc
     assert np.array_equal(a, ref)
 
 
+@pytest.mark.parametrize("piece_mb", ["1", "3", "9"])
+def test_pipelined_upload_pieces_give_the_same_answer(proof_bytes, monkeypatch, piece_mb):
+    """Proofs that all start on 4-byte boundaries go up in pieces whose upload, structure check and kernels overlap:
+    one proof per piece, five per piece and pieces large enough for the pinned staging buffers give the verdicts and
+    status codes of a single piece, with proofs of another structure (general path) in between."""
+    from stark_verifier_amd import batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    v = _variants(proof_bytes)
+    names = ["good", "witness_bit", "good", "bad_element_type", "trace_value_bit", "points_bit", "root2_bit", "good",
+             "lincomb_sibling_bit", "column_value_bit", "merkle_root_bit"]
+    blobs = [v[k] for k in names] * 3
+    assert all(len(b) % 4 == 0 for b in blobs)
+    ref_a, ref_s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert list(ref_a) == [1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 0] * 3
+    monkeypatch.setenv("STARKHIP_PIECE_MB", piece_mb)
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
+    monkeypatch.setenv("STARKHIP_HOST_THREADS", "1")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
+
+
 def _merkle_blind_hooks():
     """The oracle's hooks with MultiProof::verify replaced by one that returns the values unchecked (the reference's
     length assert at src/merkle_tree.rs:28 kept): what is left decides on the scalar checks alone."""
