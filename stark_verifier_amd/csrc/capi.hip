@@ -9,6 +9,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/starkhip.h"
@@ -67,12 +68,16 @@ struct stark_ctx {
     size_t table_budget = (size_t)8 << 30;   // twiddle tables kept across calls (STARKHIP_TABLE_MB)
     uint64_t use_counter = 0;
     std::unique_ptr<CtxAttachment> attach[CTX_SLOTS];
-    // pinned staging for copies from / to pageable host memory
-    char* pin[2] = {nullptr, nullptr};
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    bool pin_busy[2] = {false, false};  // a transfer recorded in pin_ev[i] may still read or write pin[i]
-    unsigned pin_next = 0;              // the buffer the next staged piece takes (they alternate across calls too)
-    bool pin_tried = false;
+    // pinned staging for copies from / to pageable host memory: a pair of buffers per direction, so that an upload and a
+    // download may be staged by two host threads at once
+    struct PinPair {
+        char* buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};  // a transfer recorded in ev[i] may still read or write buf[i]
+        unsigned next = 0;              // the buffer the next staged piece takes (they alternate across calls too)
+        bool tried = false;
+    } up, down;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;  // transform and download streams of the pipelined host path
     unsigned copy_threads = 8;
 };
 
@@ -82,29 +87,29 @@ namespace {
 constexpr size_t PIN_BYTES = (size_t)64 << 20;   // each of the two staging buffers
 constexpr size_t STAGE_MIN = (size_t)8 << 20;    // smaller copies go straight through hipMemcpyAsync
 
-bool pin_ready(stark_ctx* ctx) {
-    if (!ctx->pin_tried) {
-        ctx->pin_tried = true;
+bool pin_ready(stark_ctx* ctx, stark_ctx::PinPair& P) {
+    if (!P.tried) {
+        P.tried = true;
         const char* off = getenv("STARKHIP_PINNED");
         if (off && atoi(off) == 0 && *off) return false;
-        bool ok = hipHostMalloc((void**)&ctx->pin[0], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
-                  hipHostMalloc((void**)&ctx->pin[1], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
-                  hipEventCreateWithFlags(&ctx->pin_ev[0], hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ctx->pin_ev[1], hipEventDisableTiming) == hipSuccess;
+        bool ok = hipHostMalloc((void**)&P.buf[0], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void**)&P.buf[1], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
+                  hipEventCreateWithFlags(&P.ev[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&P.ev[1], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             for (int i = 0; i < 2; i++) {
-                if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
-                if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
-                ctx->pin[i] = nullptr;
-                ctx->pin_ev[i] = nullptr;
+                if (P.buf[i]) (void)hipHostFree(P.buf[i]);
+                if (P.ev[i]) (void)hipEventDestroy(P.ev[i]);
+                P.buf[i] = nullptr;
+                P.ev[i] = nullptr;
             }
         }
         if (const char* t = getenv("STARKHIP_HOST_THREADS"))
             if (atoi(t) > 0) ctx->copy_threads = (unsigned)atoi(t);
         if (ctx->copy_threads > 16) ctx->copy_threads = 16;
     }
-    return ctx->pin[0] != nullptr;
+    return P.buf[0] != nullptr;
 }
 
 void par_copy(char* dst, const char* src, size_t n, unsigned threads) {
@@ -122,58 +127,58 @@ void par_copy(char* dst, const char* src, size_t n, unsigned threads) {
 }
 }  // namespace
 
-// Before pin[b] is written again: wait for the transfer that last used it. Waiting here, not at the end of the call
+// Before buf[b] is written again: wait for the transfer that last used it. Waiting here, not at the end of the call
 // that started the transfer, lets the caller prepare its next piece while the last one is still on the link.
-static hipError_t pin_acquire(stark_ctx* ctx, unsigned b) {
-    if (!ctx->pin_busy[b]) return hipSuccess;
-    ctx->pin_busy[b] = false;
-    return hipEventSynchronize(ctx->pin_ev[b]);
+static hipError_t pin_acquire(stark_ctx::PinPair& P, unsigned b) {
+    if (!P.busy[b]) return hipSuccess;
+    P.busy[b] = false;
+    return hipEventSynchronize(P.ev[b]);
 }
 
-// Pageable host memory -> device through the two pinned buffers. On return `src` has been read completely; the last one
-// or two pieces may still be in flight on `stream`.
+// Pageable host memory -> device through the two pinned upload buffers. On return `src` has been read completely;
+// the last one or two pieces may still be in flight on `stream`.
 hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t stream) {
-    if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
+    if (n < STAGE_MIN || !ctx || !pin_ready(ctx, ctx->up)) return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
+    stark_ctx::PinPair& P = ctx->up;
     hipError_t e = hipSuccess;
     for (size_t o = 0; o < n && e == hipSuccess; o += PIN_BYTES) {
         const size_t len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-        const unsigned b = ctx->pin_next;
-        ctx->pin_next ^= 1u;
-        if ((e = pin_acquire(ctx, b)) != hipSuccess) break;
-        par_copy(ctx->pin[b], (const char*)src + o, len, ctx->copy_threads);
-        e = hipMemcpyAsync((char*)d_dst + o, ctx->pin[b], len, hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[b], stream);
-        if (e == hipSuccess) ctx->pin_busy[b] = true;
+        const unsigned b = P.next;
+        P.next ^= 1u;
+        if ((e = pin_acquire(P, b)) != hipSuccess) break;
+        par_copy(P.buf[b], (const char*)src + o, len, ctx->copy_threads);
+        e = hipMemcpyAsync((char*)d_dst + o, P.buf[b], len, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(P.ev[b], stream);
+        if (e == hipSuccess) P.busy[b] = true;
     }
     return e;
 }
 
-// Device -> pageable host memory; complete on return.
+// Device -> pageable host memory through the two pinned download buffers; complete on return.
 hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipStream_t stream) {
-    if (n < STAGE_MIN || !ctx || !pin_ready(ctx)) {
+    if (n < STAGE_MIN || !ctx || !pin_ready(ctx, ctx->down)) {
         hipError_t e = hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream);
         return e == hipSuccess ? hipStreamSynchronize(stream) : e;
     }
+    stark_ctx::PinPair& P = ctx->down;
     hipError_t e = hipSuccess;
     const size_t chunks = (n + PIN_BYTES - 1) / PIN_BYTES;
-    const unsigned first = ctx->pin_next;
     for (size_t k = 0; k <= chunks && e == hipSuccess; k++) {
         if (k < chunks) {
             const size_t o = k * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-            const unsigned b = (first + (unsigned)k) & 1u;
-            e = pin_acquire(ctx, b);
-            if (e == hipSuccess) e = hipMemcpyAsync(ctx->pin[b], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[b], stream);
-            if (e == hipSuccess) ctx->pin_busy[b] = true;
+            const unsigned b = (unsigned)k & 1u;
+            e = pin_acquire(P, b);
+            if (e == hipSuccess) e = hipMemcpyAsync(P.buf[b], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(P.ev[b], stream);
+            if (e == hipSuccess) P.busy[b] = true;
         }
         if (k >= 1 && e == hipSuccess) {
             const size_t o = (k - 1) * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
-            const unsigned b = (first + (unsigned)(k - 1)) & 1u;
-            e = pin_acquire(ctx, b);
-            if (e == hipSuccess) par_copy((char*)dst + o, ctx->pin[b], len, ctx->copy_threads);
+            const unsigned b = (unsigned)(k - 1) & 1u;
+            e = pin_acquire(P, b);
+            if (e == hipSuccess) par_copy((char*)dst + o, P.buf[b], len, ctx->copy_threads);
         }
     }
-    ctx->pin_next = (first + (unsigned)chunks) & 1u;
     return e;
 }
 
@@ -696,6 +701,111 @@ int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, si
     return run_plan(ctx, plan, (const uint32_t*)d_in, (uint32_t*)d_out, batch, stream);
 }
 
+// Host buffers, more than one staging buffer of polynomials: groups of `per_group` polynomials go through three stages
+// that overlap, each with its own stream and host thread: a helper thread stages group g + 1 into the device buffer
+// (ctx->io) while this thread queues the transform of group g behind its upload event and a second helper thread
+// drains group g - 1 behind its transform event. The link carries both directions at once, so a batch costs about
+// one direction's transfer time instead of two plus the transforms.
+int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch, size_t per_group, NttPlan* plan) {
+    const size_t poly_bytes = (size_t)32 << log_n, poly_words = (size_t)8 << log_n;
+    const size_t groups = (batch + per_group - 1) / per_group;
+    if (!ctx->stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    // the multi-pass intermediate is sized before anything is queued: growing it later would free memory in use
+    if (plan->passes.size() > 1) {
+        const size_t per_call = std::min(per_group, std::max<size_t>(1, ctx->chunk_bytes / poly_bytes));
+        int rc = ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, per_call * ((size_t)1 << log_n) * ntt29_mid_bytes());
+        if (rc != STARK_OK) return rc;
+    }
+    std::vector<hipEvent_t> up(groups, nullptr), done(groups, nullptr);
+    auto drop_events = [&] {
+        for (hipEvent_t e : up)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : done)
+            if (e) (void)hipEventDestroy(e);
+    };
+    for (size_t g = 0; g < groups; g++)
+        if (hipEventCreateWithFlags(&up[g], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&done[g], hipEventDisableTiming) != hipSuccess) {
+            drop_events();
+            return fail(ctx, STARK_ERR_HIP, "event creation failed");
+        }
+    uint32_t* d = (uint32_t*)ctx->io;
+    // two staging threads at once: six copy threads each measured best on 16 host cores (8: +5 %, 12: +15 % time)
+    const unsigned saved_threads = ctx->copy_threads;
+    (void)pin_ready(ctx, ctx->up);  // reads STARKHIP_HOST_THREADS on first use
+    if (ctx->copy_threads > 6 && !getenv("STARKHIP_HOST_THREADS")) ctx->copy_threads = 6;
+    std::atomic<size_t> uploaded{0}, transformed{0};
+    std::atomic<int> up_err{0}, down_err{0};
+    auto count_of = [&](size_t g) { return std::min(per_group, batch - g * per_group); };
+    std::thread uploader([&] {
+        hipError_t e = hipSetDevice(ctx->device);  // the current device is per thread
+        for (size_t g = 0; g < groups; g++) {
+            if (e == hipSuccess)
+                e = copy_h2d(ctx, d + g * per_group * poly_words, limbs + g * per_group * poly_words, count_of(g) * poly_bytes, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(up[g], ctx->stream);
+            if (e != hipSuccess) up_err.store((int)e);
+            uploaded.store(g + 1, std::memory_order_release);  // also after an error: nobody may wait for ever
+        }
+    });
+    // The download is pipelined by hand (copy_d2h completes one call before the next starts): the transfer of group g
+    // into one pinned buffer is queued before group g - 1 is copied out of the other.
+    const bool staged_down = per_group * poly_bytes <= PIN_BYTES && pin_ready(ctx, ctx->down);
+    std::thread downloader([&] {
+        hipError_t e = hipSetDevice(ctx->device);
+        stark_ctx::PinPair& P = ctx->down;
+        for (size_t g = 0; g <= groups; g++) {
+            if (g < groups) {
+                while (transformed.load(std::memory_order_acquire) <= g) std::this_thread::yield();
+                if (up_err.load() || down_err.load()) break;  // the main thread stopped queueing: nothing more to fetch
+                const size_t off = g * per_group * poly_words, len = count_of(g) * poly_bytes;
+                if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream3, done[g], 0);
+                if (!staged_down) {
+                    if (e == hipSuccess) e = copy_d2h(ctx, limbs + off, d + off, len, ctx->stream3);
+                } else {
+                    if (e == hipSuccess) e = hipMemcpyAsync(P.buf[g & 1], d + off, len, hipMemcpyDeviceToHost, ctx->stream3);
+                    if (e == hipSuccess) e = hipEventRecord(P.ev[g & 1], ctx->stream3);
+                }
+            }
+            if (staged_down && g >= 1 && e == hipSuccess) {
+                const size_t off = (g - 1) * per_group * poly_words, len = count_of(g - 1) * poly_bytes;
+                e = hipEventSynchronize(P.ev[(g - 1) & 1]);
+                if (e == hipSuccess) par_copy((char*)(limbs + off), P.buf[(g - 1) & 1], len, ctx->copy_threads);
+            }
+            if (e != hipSuccess) {
+                down_err.store((int)e);
+                break;
+            }
+        }
+    });
+    int rc = STARK_OK;
+    for (size_t g = 0; g < groups; g++) {
+        while (uploaded.load(std::memory_order_acquire) <= g) std::this_thread::yield();
+        if (rc == STARK_OK && !up_err.load()) {
+            hipError_t e = hipStreamWaitEvent(ctx->stream2, up[g], 0);
+            if (e != hipSuccess) rc = fail(ctx, STARK_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+            uint32_t* dg = d + g * per_group * poly_words;
+            if (rc == STARK_OK) rc = run_plan(ctx, plan, dg, dg, count_of(g), ctx->stream2);
+            if (rc == STARK_OK && (e = hipEventRecord(done[g], ctx->stream2)) != hipSuccess)
+                rc = fail(ctx, STARK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+            if (rc != STARK_OK) down_err.store((int)hipErrorUnknown);  // tells the downloader to skip the rest
+        }
+        transformed.store(g + 1, std::memory_order_release);
+    }
+    uploader.join();
+    downloader.join();
+    ctx->copy_threads = saved_threads;
+    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->stream2), e3 = hipStreamSynchronize(ctx->stream3);
+    drop_events();
+    if (rc != STARK_OK) return rc;
+    if (up_err.load()) return fail(ctx, STARK_ERR_HIP, "staged upload: %s", hipGetErrorString((hipError_t)up_err.load()));
+    if (down_err.load()) return fail(ctx, STARK_ERR_HIP, "staged download: %s", hipGetErrorString((hipError_t)down_err.load()));
+    HIP_TRY(ctx, e1);
+    HIP_TRY(ctx, e2);
+    HIP_TRY(ctx, e3);
+    return STARK_OK;
+}
+
 // ---- column transforms of a row-major [2^log_n][cols] matrix (cols a power of two) ------------------------------
 // Every column is one polynomial (element stride cols, polynomial stride 1): what stage C of a sharded transform
 // needs, where the matrix is the [n1][n2 / world] block the all-to-all leaves on a rank. Adjacent columns are adjacent
@@ -1016,11 +1126,14 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     for (auto& p : ctx->stage_a_tabs) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->pin_busy[i]) (void)hipEventSynchronize(ctx->pin_ev[i]);  // a transfer on a caller's stream
-        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
-        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
-    }
+    for (stark_ctx::PinPair* P : {&ctx->up, &ctx->down})
+        for (int i = 0; i < 2; i++) {
+            if (P->busy[i]) (void)hipEventSynchronize(P->ev[i]);  // a transfer on a caller's stream
+            if (P->buf[i]) (void)hipHostFree(P->buf[i]);
+            if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
+        }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1122,6 +1235,17 @@ int stark_ntt_batch(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batc
     size_t bytes = (batch << log_n) * 32;
     int rc = ensure_buffer(ctx, &ctx->io, &ctx->io_bytes, bytes);
     if (rc != STARK_OK) return rc;
+    {
+        // several staging buffers' worth of polynomials: upload, transform and download overlap group by group
+        const bool pipelined = env_int("STARKHIP_HOST_PIPELINE", 1) != 0;
+        const size_t poly_bytes = (size_t)32 << log_n;
+        const size_t per_group = poly_bytes >= PIN_BYTES / 2 ? 1 : PIN_BYTES / 2 / poly_bytes;  // half a staging buffer
+        if (pipelined && batch > per_group && bytes >= 2 * STAGE_MIN) {
+            NttPlan* plan;
+            if ((rc = get_plan(ctx, log_n, r, inverse != 0, &plan)) != STARK_OK) return rc;
+            return ntt_host_pipelined(ctx, limbs, log_n, batch, per_group, plan);
+        }
+    }
     HIP_TRY(ctx, copy_h2d(ctx, ctx->io, limbs, bytes, ctx->stream));
     rc = ntt_common(ctx, ctx->io, ctx->io, log_n, batch, root_of_unity, inverse, ctx->stream);
     if (rc != STARK_OK) return rc;

@@ -194,6 +194,26 @@ def test_ntt_two_pass_intermediate_layouts_agree(sv, log_n, split, logc, monkeyp
             assert np.array_equal(outs[0][1][b], oracle.fft_inv(x[b], w))
 
 
+@pytest.mark.parametrize("log_n,batch", [(16, 70), (21, 3), (10, 5000), (13, 300)])
+def test_ntt_host_buffers_pipelined_equals_sequential(sv, log_n, batch, monkeypatch):
+    """Host-buffer batches larger than one staging buffer are uploaded, transformed and downloaded group by group on
+    three streams; STARKHIP_HOST_PIPELINE=0 keeps the three steps in sequence. Same outputs, both directions, and equal
+    to the oracle on the first, a middle and the last polynomial."""
+    n = 1 << log_n
+    w = root_of_unity(log_n)
+    x = synth.field_elements(synth.SEED + 400 + log_n, batch * n).reshape(batch, n, 8)
+    for inverse in (False, True):
+        monkeypatch.setenv("STARKHIP_HOST_PIPELINE", "1")
+        a = sv.fft.ntt_batch(x, w, inverse=inverse)
+        monkeypatch.setenv("STARKHIP_HOST_PIPELINE", "0")
+        b = sv.fft.ntt_batch(x, w, inverse=inverse)
+        assert np.array_equal(a, b)
+        if log_n <= 16:
+            for i in (0, batch // 2, batch - 1):
+                want = oracle.fft_inv(x[i], w) if inverse else oracle.fft_fwd(x[i], w)
+                assert np.array_equal(a[i], want), (inverse, i)
+
+
 def test_ntt_linearity_2p20(sv):
     log_n, n = 20, 1 << 20
     w = root_of_unity(log_n)
