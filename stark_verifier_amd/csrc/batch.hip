@@ -699,18 +699,22 @@ static int verify_impl(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* of
             // the helper thread's staging copies use half of the host threads
             const unsigned saved_threads = threads;
             threads = std::max(1u, threads / 2);
-            for (size_t p = 0; p + 1 < cuts.size() && rc == STARK_OK; p++) {
-                const size_t i0 = cuts[p], i1 = cuts[p + 1], k0 = who.size();
-                double tc = now();
-                classify(i0, i1);
-                t_classify += now() - tc;
-                for (size_t i = i0; i < i1; i++)
-                    if (canon[i]) {
-                        bases[who.size()] = offsets[c0 + i] - offsets[c0];
-                        who.push_back(i);
-                    }
-                make_io(who, k0, who.size(), io);
-                rc = fast_session_piece(ctx, ses, bases.data() + k0, io.data() + 16 * k0, who.size() - k0, CP, d_mini);
+            try {  // nothing may unwind past the session's running upload thread
+                for (size_t p = 0; p + 1 < cuts.size() && rc == STARK_OK; p++) {
+                    const size_t i0 = cuts[p], i1 = cuts[p + 1], k0 = who.size();
+                    double tc = now();
+                    classify(i0, i1);
+                    t_classify += now() - tc;
+                    for (size_t i = i0; i < i1; i++)
+                        if (canon[i]) {
+                            bases[who.size()] = offsets[c0 + i] - offsets[c0];
+                            who.push_back(i);
+                        }
+                    make_io(who, k0, who.size(), io);
+                    rc = fast_session_piece(ctx, ses, bases.data() + k0, io.data() + 16 * k0, who.size() - k0, CP, d_mini);
+                }
+            } catch (...) {
+                rc = STARK_ERR_NOMEM;
             }
             threads = saved_threads;
             std::vector<uint8_t> st(who.size());

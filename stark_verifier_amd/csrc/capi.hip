@@ -782,12 +782,16 @@ int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t b
     for (size_t g = 0; g < groups; g++) {
         while (uploaded.load(std::memory_order_acquire) <= g) std::this_thread::yield();
         if (rc == STARK_OK && !up_err.load()) {
-            hipError_t e = hipStreamWaitEvent(ctx->stream2, up[g], 0);
-            if (e != hipSuccess) rc = fail(ctx, STARK_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
-            uint32_t* dg = d + g * per_group * poly_words;
-            if (rc == STARK_OK) rc = run_plan(ctx, plan, dg, dg, count_of(g), ctx->stream2);
-            if (rc == STARK_OK && (e = hipEventRecord(done[g], ctx->stream2)) != hipSuccess)
-                rc = fail(ctx, STARK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+            try {  // nothing may unwind past the two running threads
+                hipError_t e = hipStreamWaitEvent(ctx->stream2, up[g], 0);
+                if (e != hipSuccess) rc = fail(ctx, STARK_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+                uint32_t* dg = d + g * per_group * poly_words;
+                if (rc == STARK_OK) rc = run_plan(ctx, plan, dg, dg, count_of(g), ctx->stream2);
+                if (rc == STARK_OK && (e = hipEventRecord(done[g], ctx->stream2)) != hipSuccess)
+                    rc = fail(ctx, STARK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+            } catch (...) {
+                rc = STARK_ERR_NOMEM;
+            }
             if (rc != STARK_OK) down_err.store((int)hipErrorUnknown);  // tells the downloader to skip the rest
         }
         transformed.store(g + 1, std::memory_order_release);
