@@ -23,9 +23,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# device memory shared between the ranks' processes (RCCL) needs dmabuf IPC on this driver
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
