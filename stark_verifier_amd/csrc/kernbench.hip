@@ -10,6 +10,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "blake2s.cuh"
 #include "field.cuh"
 #include "field29.cuh"
@@ -139,6 +141,265 @@ __global__ void __launch_bounds__(256) k_femul29_uniform(Stamp* st, uint32_t* si
     if (acc == 0x1234567) sink[0] = acc;
 }
 
+
+// ---- product-only bake-off: 9 x 9 limbs of 29 bits -> 18 normalized limbs, no reduction mod p ----------------------
+// Three ways to form the 17 column sums of a 261-bit x 261-bit product, timed alone and checked against each other:
+// schoolbook (81 multiply-adds), one level of Karatsuba over three blocks of three limbs (54 signed multiply-adds,
+// 18 operand differences, 23 64-bit additions to place the shared block products), and FP64 fused multiply-adds on
+// five 52-bit limbs (25 products, each split into a high and a low half by two v_fma_f64 and one v_add_f64 under
+// round-toward-zero, the halves summed as integer bit patterns).
+struct Prod18 {
+    uint32_t l[18];
+};
+
+__device__ __forceinline__ void norm_cols(const uint64_t (&col)[17], Prod18& r) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 17; c++) {
+        acc += col[c];
+        r.l[c] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    r.l[17] = (uint32_t)acc;
+}
+
+__device__ __forceinline__ Prod18 prod_school(const F29& x, const F29& y) {
+    Prod18 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 17; c++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = c - i;
+            if (j >= 0 && j < 9) acc = mad64(x.l[i], y.l[j], acc);
+        }
+        r.l[c] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    r.l[17] = (uint32_t)acc;
+    return r;
+}
+
+__device__ __forceinline__ int64_t smad64(int32_t a, int32_t b, int64_t c) { return (int64_t)a * b + c; }
+
+// columns of a 3 x 3 block product, each chain started from seed[i]
+__device__ __forceinline__ void block_u(const uint32_t* a, const uint32_t* b, const uint64_t (&seed)[5], uint64_t (&out)[5]) {
+    out[0] = mad64(a[0], b[0], seed[0]);
+    out[1] = mad64(a[1], b[0], mad64(a[0], b[1], seed[1]));
+    out[2] = mad64(a[2], b[0], mad64(a[1], b[1], mad64(a[0], b[2], seed[2])));
+    out[3] = mad64(a[2], b[1], mad64(a[1], b[2], seed[3]));
+    out[4] = mad64(a[2], b[2], seed[4]);
+}
+__device__ __forceinline__ void block_s(const int32_t* a, const int32_t* b, const uint64_t (&seed)[5], uint64_t (&out)[5]) {
+    out[0] = (uint64_t)smad64(a[0], b[0], (int64_t)seed[0]);
+    out[1] = (uint64_t)smad64(a[1], b[0], smad64(a[0], b[1], (int64_t)seed[1]));
+    out[2] = (uint64_t)smad64(a[2], b[0], smad64(a[1], b[1], smad64(a[0], b[2], (int64_t)seed[2])));
+    out[3] = (uint64_t)smad64(a[2], b[1], smad64(a[1], b[2], (int64_t)seed[3]));
+    out[4] = (uint64_t)smad64(a[2], b[2], (int64_t)seed[4]);
+}
+
+__device__ __forceinline__ Prod18 prod_karatsuba(const F29& x, const F29& y) {
+    const uint32_t *a = x.l, *b = y.l;
+    const uint64_t zero[5] = {0, 0, 0, 0, 0};
+    uint64_t D0[5], D1[5], D2[5];
+    block_u(a, b, zero, D0);
+    block_u(a + 3, b + 3, zero, D1);
+    block_u(a + 6, b + 6, zero, D2);
+    // A_i B_j + A_j B_i = D_i + D_j + (A_j - A_i)(B_i - B_j)
+    int32_t da01[3], db01[3], da02[3], db02[3], da12[3], db12[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        da01[k] = (int32_t)(a[3 + k] - a[k]);
+        db01[k] = (int32_t)(b[k] - b[3 + k]);
+        da02[k] = (int32_t)(a[6 + k] - a[k]);
+        db02[k] = (int32_t)(b[k] - b[6 + k]);
+        da12[k] = (int32_t)(a[6 + k] - a[3 + k]);
+        db12[k] = (int32_t)(b[3 + k] - b[6 + k]);
+    }
+    uint64_t S01[5], S012[5], S12[5], T1[5], T2[5], T3[5], seed[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        S01[i] = D0[i] + D1[i];
+        S012[i] = S01[i] + D2[i];
+        S12[i] = D1[i] + D2[i];
+    }
+    // block t of the result starts at column 3 t: neighbours overlap in two columns, added through the chain seeds
+#pragma unroll
+    for (int i = 0; i < 5; i++) seed[i] = S01[i] + (i < 2 ? D0[3 + i] : 0);
+    block_s(da01, db01, seed, T1);
+#pragma unroll
+    for (int i = 0; i < 5; i++) seed[i] = S012[i] + (i < 2 ? T1[3 + i] : 0);
+    block_s(da02, db02, seed, T2);
+#pragma unroll
+    for (int i = 0; i < 5; i++) seed[i] = S12[i] + (i < 2 ? T2[3 + i] : 0);
+    block_s(da12, db12, seed, T3);
+    uint64_t col[17];
+    col[0] = D0[0]; col[1] = D0[1]; col[2] = D0[2];
+    col[3] = T1[0]; col[4] = T1[1]; col[5] = T1[2];
+    col[6] = T2[0]; col[7] = T2[1]; col[8] = T2[2];
+    col[9] = T3[0]; col[10] = T3[1]; col[11] = T3[2];
+    col[12] = D2[0] + T3[3]; col[13] = D2[1] + T3[4]; col[14] = D2[2]; col[15] = D2[3]; col[16] = D2[4];
+    Prod18 r;
+    norm_cols(col, r);
+    return r;
+}
+
+// 261 bits as five 52-bit limbs held as doubles (exact integers below 2^53)
+struct F52 {
+    double l[5];
+};
+__device__ __forceinline__ double u52_to_double(uint64_t k) {  // k < 2^52
+    return __longlong_as_double((long long)(0x4330000000000000ull | k)) - 4503599627370496.0;
+}
+__device__ __forceinline__ F52 f52_from_29(const uint32_t* a) {  // nine 29-bit limbs -> five 52-bit limbs
+    uint64_t w[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, k = bit / 52, sh = bit % 52;
+        w[k] |= ((uint64_t)a[i] << sh) & 0xFFFFFFFFFFFFFull;
+        if (sh + 29 > 52 && k + 1 < 5) w[k + 1] |= (uint64_t)a[i] >> (52 - sh);
+    }
+    F52 r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = u52_to_double(w[i]);
+    return r;
+}
+// ten 52-bit columns (normalized) of the product; needs round-toward-zero for f64 (set by the kernel)
+__device__ __forceinline__ void prod_fp64(const F52& x, const F52& y, uint64_t (&out)[10]) {
+    const double C1 = 20282409603651670423947251286016.0;                  // 2^104
+    const double C2 = 20282409603651670423947251286016.0 + 4503599627370496.0;  // 2^104 + 2^52
+    uint64_t hi_sum[10], lo_sum[10];
+#pragma unroll
+    for (int c = 0; c < 10; c++) hi_sum[c] = lo_sum[c] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            // in assembly: the compiler restores round-to-nearest in front of the f64 instructions it emits itself
+            double hi, sub, lo;
+            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(hi) : "v"(x.l[i]), "v"(y.l[j]), "v"(C1));
+            asm volatile("v_add_f64 %0, %1, -%2" : "=v"(sub) : "v"(C2), "v"(hi));
+            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(lo) : "v"(x.l[i]), "v"(y.l[j]), "v"(sub));
+            hi_sum[i + j + 1] += (uint64_t)__double_as_longlong(hi);
+            lo_sum[i + j] += (uint64_t)__double_as_longlong(lo);
+        }
+    // bit patterns: hi = 0x4670.. | h (h = floor(ab / 2^52) < 2^52), lo = 0x4330.. | l
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 10; c++) {
+        const int nlo = c < 5 ? c + 1 : 9 - c, nhi = c == 0 ? 0 : (c <= 5 ? c : 10 - c);
+        acc += lo_sum[c] - (uint64_t)nlo * 0x4330000000000000ull + hi_sum[c] - (uint64_t)nhi * 0x4670000000000000ull;
+        out[c] = acc & 0xFFFFFFFFFFFFFull;
+        acc >>= 52;
+    }
+}
+
+// Round-toward-zero for f64 in this wave's MODE register, written in assembly (the compiler tracks its own writes of the
+// register and would put round-to-nearest back); the operands pass through an empty volatile asm behind it.
+__device__ __forceinline__ void f64_round_toward_zero(F52& a, F52& b) {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        asm volatile("" : "+v"(a.l[i]));
+        asm volatile("" : "+v"(b.l[i]));
+    }
+}
+
+__device__ __forceinline__ F29 seed_tight(uint32_t s) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (s * (2654435761u + 40503u * i) + i * 977u) & F29_MASK;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_prod_school(Stamp* st, uint32_t* sink, uint32_t s) {
+    F29 a = seed_tight(s + threadIdx.x), b = seed_tight(s * 3 + blockIdx.x);
+    unsigned long long c0, r0;
+    stamp_begin(c0, r0);
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+        const Prod18 p = prod_school(a, b);
+#pragma unroll
+        for (int i = 0; i < 9; i++) a.l[i] = p.l[i] ^ p.l[9 + i];
+    }
+    stamp_end(st, c0, r0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 9; i++) acc ^= a.l[i];
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_prod_kara(Stamp* st, uint32_t* sink, uint32_t s) {
+    F29 a = seed_tight(s + threadIdx.x), b = seed_tight(s * 3 + blockIdx.x);
+    unsigned long long c0, r0;
+    stamp_begin(c0, r0);
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+        const Prod18 p = prod_karatsuba(a, b);
+#pragma unroll
+        for (int i = 0; i < 9; i++) a.l[i] = p.l[i] ^ p.l[9 + i];
+    }
+    stamp_end(st, c0, r0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 9; i++) acc ^= a.l[i];
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_prod_fp64(Stamp* st, uint32_t* sink, uint32_t s) {
+    const F29 a29 = seed_tight(s + threadIdx.x), b29 = seed_tight(s * 3 + blockIdx.x);
+    F52 a = f52_from_29(a29.l);
+    F52 b = f52_from_29(b29.l);
+    f64_round_toward_zero(a, b);
+    unsigned long long c0, r0;
+    stamp_begin(c0, r0);
+    uint64_t col[10];
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+        prod_fp64(a, b, col);
+#pragma unroll
+        for (int i = 0; i < 5; i++) a.l[i] = u52_to_double(col[i] ^ col[5 + i]);  // back to limbs for the next product
+    }
+    stamp_end(st, c0, r0);
+    uint64_t acc = 0;
+    for (int i = 0; i < 10; i++) acc ^= col[i];
+    if (acc == 0x1234567) sink[0] = (uint32_t)acc;
+}
+
+// The three forms on the same 65536 operand pairs, one kernel each (form 0 schoolbook, 1 Karatsuba, 2 FP64): the product
+// as 17 words of 32 bits per pair, compared on the host.
+__device__ __forceinline__ void check_operands(uint32_t t, uint32_t s, F29& a, F29& b) {
+    a = seed_tight(s + t * 7919u);
+    b = seed_tight(s * 3 + t * 104729u);
+    if (t % 5 == 0)
+        for (int i = 0; i < 9; i++) a.l[i] = F29_MASK;  // all-ones operands
+    if (t % 7 == 0)
+        for (int i = 0; i < 9; i++) b.l[i] = (i & 1) ? F29_MASK : 0;
+    a.l[8] &= 0x00FFFFFFu;  // 256-bit operands (five 52-bit limbs hold 260 bits)
+    b.l[8] &= 0x00FFFFFFu;
+    // hipcc 7.2 turns (x & 0xFFFFFF) * (y & 0xFFFFFF) + acc into a 24-bit multiply, drops the masks as no longer needed,
+    // and then selects the full 32-bit v_mad_u64_u32 on the unmasked registers: the masked values are hidden from it
+    asm volatile("" : "+v"(a.l[8]), "+v"(b.l[8]));
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(256) k_prod_check(uint32_t* out, uint32_t s) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    F29 a, b;
+    check_operands(t, s, a, b);
+    uint32_t w[17];
+    for (int i = 0; i < 17; i++) w[i] = 0;
+    if (FORM == 2) {
+        F52 fa = f52_from_29(a.l), fb = f52_from_29(b.l);
+        f64_round_toward_zero(fa, fb);
+        uint64_t col[10];
+        prod_fp64(fa, fb, col);
+        for (int k = 0; k < 520; k++) w[k / 32] |= ((uint32_t)(col[k / 52] >> (k % 52)) & 1u) << (k % 32);
+    } else {
+        const Prod18 p = FORM == 0 ? prod_school(a, b) : prod_karatsuba(a, b);
+        for (int k = 0; k < 522; k++) w[k / 32] |= ((p.l[k / 29] >> (k % 29)) & 1u) << (k % 32);
+    }
+    for (int i = 0; i < 17; i++) out[17 * (size_t)t + i] = w[i];
+}
+
 __global__ void __launch_bounds__(256) k_butterfly29(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 x = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), y = f29_from_fe(fe_canon(seed_fe(s * 5 + threadIdx.x)));
     F29 w = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
@@ -222,6 +483,45 @@ int main(int argc, char** argv) {
     run("f29_mul_split", k_femul29_split, blocks, d_st, h_st, d_sink);
     run("f29_mul_unif2", k_femul29_uniform, blocks, d_st, h_st, d_sink);
     run("butterfly29", k_butterfly29, blocks, d_st, h_st, d_sink);
+    {
+        const size_t n = 65536, words = 17 * n;
+        uint32_t* d_out;
+        std::vector<uint32_t> h[3];
+        CHECK(hipMalloc(&d_out, 4 * words));
+        for (int f = 0; f < 3; f++) {
+            h[f].resize(words);
+            if (f == 0) hipLaunchKernelGGL(k_prod_check<0>, dim3(256), dim3(256), 0, 0, d_out, 12345u);
+            if (f == 1) hipLaunchKernelGGL(k_prod_check<1>, dim3(256), dim3(256), 0, 0, d_out, 12345u);
+            if (f == 2) hipLaunchKernelGGL(k_prod_check<2>, dim3(256), dim3(256), 0, 0, d_out, 12345u);
+            CHECK(hipMemcpy(h[f].data(), d_out, 4 * words, hipMemcpyDeviceToHost));
+        }
+        if (getenv("KERNBENCH_DUMP")) {
+            const size_t t = (size_t)atoi(getenv("KERNBENCH_DUMP"));
+            for (int f = 0; f < 3; f++) {
+                printf("form %d:", f);
+                for (int i = 0; i < 17; i++) printf(" %08x", h[f][17 * t + i]);
+                printf("\n");
+            }
+        }
+        size_t bad_k = 0, bad_f = 0, nonzero = 0;
+        for (size_t t = 0; t < n; t++) {
+            bool k = true, f = true, nz = false;
+            for (int i = 0; i < 17; i++) {
+                k = k && h[0][17 * t + i] == h[1][17 * t + i];
+                f = f && h[0][17 * t + i] == h[2][17 * t + i];
+                nz = nz || h[0][17 * t + i] != 0;
+            }
+            bad_k += !k;
+            bad_f += !f;
+            nonzero += nz;
+        }
+        printf("product forms agree on %zu operand pairs (%zu non-zero products): %s (Karatsuba form: %zu mismatches, FP64 form: %zu)\n",
+               n, nonzero, bad_k + bad_f ? "NO" : "yes", bad_k, bad_f);
+        CHECK(hipFree(d_out));
+    }
+    run("prod_school", k_prod_school, blocks, d_st, h_st, d_sink);
+    run("prod_karatsuba", k_prod_kara, blocks, d_st, h_st, d_sink);
+    run("prod_fp64", k_prod_fp64, blocks, d_st, h_st, d_sink);
     run("blake2s", k_blake2s, blocks, d_st, h_st, d_sink);
     return 0;
 }
