@@ -343,23 +343,31 @@ struct Buckets {
     uint32_t base[8], count[8];
 };
 
-// the verdict; lane = proof. 4 a branch's root differs; else the first failing scalar check; else 0
+// the verdict; one wavefront per proof. 4 a branch's root differs; else the first failing scalar check (FRI lanes in
+// order, then the constraint lanes); else 0
 __global__ void __launch_bounds__(64)
 vstatus_kernel(uint32_t m, Buckets B, const uint8_t* __restrict__ acc, const uint8_t* __restrict__ check, uint8_t* __restrict__ status) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = blockIdx.x, lane = threadIdx.x;
     if (p >= m) return;
     uint32_t bad = 0;
     for (uint32_t b = 0; b < B.n; b++) {
         const uint8_t* a = acc + (size_t)B.base[b] * m + (size_t)p * B.count[b];
-        for (uint32_t k = 0; k < B.count[b]; k++) bad |= a[k] ^ 1u;
+        for (uint32_t k = lane; k < B.count[b]; k += 64) bad |= a[k] ^ 1u;
     }
-    uint8_t st = bad ? 4 : 0;
-    // FRI lanes of all proofs come first, then the constraint lanes
+    // FRI lanes of all proofs come first, then the constraint lanes; key = (index, code) of a lane's first failure
     const uint8_t* f = check + (size_t)p * N_FRI;
-    for (uint32_t k = 0; k < N_FRI && !st; k++) st = f[k];
     const uint8_t* c = check + (size_t)m * N_FRI + (size_t)p * SPOT;
-    for (uint32_t k = 0; k < SPOT && !st; k++) st = c[k];
-    status[p] = st;
+    uint32_t key = 0xFFFFFFFFu;
+    for (uint32_t k = lane; k < N_FRI + SPOT; k += 64) {
+        const uint32_t v = k < N_FRI ? f[k] : c[k - N_FRI];
+        if (v && key == 0xFFFFFFFFu) key = (k << 8) | v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)key, off, 64);
+        key = other < key ? other : key;
+    }
+    const bool any_bad = __ballot(bad != 0) != 0;
+    if (lane == 0) status[p] = any_bad ? 4 : (key == 0xFFFFFFFFu ? 0 : (uint8_t)(key & 0xFFu));
 }
 
 }  // namespace
@@ -496,7 +504,7 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, st));
     F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
                                   d + o_chk + (size_t)N_FRI * m, st));
-    hipLaunchKernelGGL(vstatus_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
+    hipLaunchKernelGGL(vstatus_kernel, dim3(m), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
     F_TRY(hipGetLastError());
     return STARK_OK;
 }
