@@ -396,6 +396,14 @@ static uint8_t field_checks(const ProofWork& pw, const Params& P, size_t gi) {
     return ST_ACCEPT;
 }
 
+// f(i) for every i below n on up to `threads` host threads. The threads are kept between calls (one pool per process);
+// a second context calling at the same moment starts its own, as every call did before the pool existed.
+static WorkerPool& host_pool() {
+    static WorkerPool pool(15);
+    return pool;
+}
+static std::mutex host_pool_mutex;
+
 template <class F>
 static void parallel_for(size_t n, unsigned threads, F f) {
     if (threads <= 1 || n <= 1) {
@@ -403,11 +411,17 @@ static void parallel_for(size_t n, unsigned threads, F f) {
         return;
     }
     std::atomic<size_t> next{0};
+    const size_t tasks = std::min<size_t>(threads, n);
+    auto body = [&](size_t) {
+        for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+    };
+    std::unique_lock<std::mutex> lk(host_pool_mutex, std::try_to_lock);
+    if (lk.owns_lock()) {
+        host_pool().run(tasks, body);
+        return;
+    }
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < std::min<size_t>(threads, n); t++)
-        pool.emplace_back([&] {
-            for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
-        });
+    for (size_t t = 0; t < tasks; t++) pool.emplace_back([&] { body(t); });
     for (auto& th : pool) th.join();
 }
 

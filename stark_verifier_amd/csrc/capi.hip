@@ -76,6 +76,7 @@ struct stark_ctx {
         bool busy[2] = {false, false};  // a transfer recorded in ev[i] may still read or write buf[i]
         unsigned next = 0;              // the buffer the next staged piece takes (they alternate across calls too)
         bool tried = false;
+        std::unique_ptr<WorkerPool> pool;  // the host threads that fill or drain the buffers
     } up, down;
     hipStream_t stream2 = nullptr, stream3 = nullptr;  // transform and download streams of the pipelined host path
     unsigned copy_threads = 8;
@@ -112,18 +113,17 @@ bool pin_ready(stark_ctx* ctx, stark_ctx::PinPair& P) {
     return P.buf[0] != nullptr;
 }
 
-void par_copy(char* dst, const char* src, size_t n, unsigned threads) {
+void par_copy(char* dst, const char* src, size_t n, unsigned threads, stark_ctx::PinPair& P) {
     if (threads <= 1 || n < ((size_t)1 << 20)) {
         memcpy(dst, src, n);
         return;
     }
-    std::vector<std::thread> pool;
+    if (!P.pool) P.pool.reset(new WorkerPool(threads - 1));  // the caller is the last of the `threads`
     const size_t per = ((n + threads - 1) / threads + 4095) & ~(size_t)4095;
-    for (unsigned i = 0; i < threads; i++) {
+    P.pool->run(threads, [&](size_t i) {
         const size_t lo = per * i, hi = lo + per < n ? lo + per : n;
-        if (lo < hi) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
-    }
-    for (auto& t : pool) t.join();
+        if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
+    });
 }
 }  // namespace
 
@@ -146,7 +146,7 @@ hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipS
         const unsigned b = P.next;
         P.next ^= 1u;
         if ((e = pin_acquire(P, b)) != hipSuccess) break;
-        par_copy(P.buf[b], (const char*)src + o, len, ctx->copy_threads);
+        par_copy(P.buf[b], (const char*)src + o, len, ctx->copy_threads, P);
         e = hipMemcpyAsync((char*)d_dst + o, P.buf[b], len, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipEventRecord(P.ev[b], stream);
         if (e == hipSuccess) P.busy[b] = true;
@@ -176,7 +176,7 @@ hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipS
             const size_t o = (k - 1) * PIN_BYTES, len = n - o < PIN_BYTES ? n - o : PIN_BYTES;
             const unsigned b = (unsigned)(k - 1) & 1u;
             e = pin_acquire(P, b);
-            if (e == hipSuccess) par_copy((char*)dst + o, P.buf[b], len, ctx->copy_threads);
+            if (e == hipSuccess) par_copy((char*)dst + o, P.buf[b], len, ctx->copy_threads, P);
         }
     }
     return e;
@@ -770,7 +770,7 @@ int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t b
             if (staged_down && g >= 1 && e == hipSuccess) {
                 const size_t off = (g - 1) * per_group * poly_words, len = count_of(g - 1) * poly_bytes;
                 e = hipEventSynchronize(P.ev[(g - 1) & 1]);
-                if (e == hipSuccess) par_copy((char*)(limbs + off), P.buf[(g - 1) & 1], len, ctx->copy_threads);
+                if (e == hipSuccess) par_copy((char*)(limbs + off), P.buf[(g - 1) & 1], len, ctx->copy_threads, P);
             }
             if (e != hipSuccess) {
                 down_err.store((int)e);
