@@ -75,6 +75,20 @@ def test_host_mirror_shape_checks_happen_before_any_device_call():
         mt.MultiProof([mt.ProofBranch([bytes(32)], bytes(32), bytes(32))], bytes(32)).verify([1, 2])
 
 
+def test_worker_pool_stress(tmp_path):
+    """The host thread pool behind the staging copies and the batch driver's loops (csrc/worker_pool.hpp, pure C++):
+    every task index runs exactly once for task counts around the worker count over many generations, closures do not
+    outlive their run, two pools work side by side. Built with ThreadSanitizer where the toolchain has it."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = os.path.join(root, "tests", "worker_pool_test.cpp")
+    exe = str(tmp_path / "worker_pool_test")
+    base = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src]
+    if subprocess.run(base[:4] + ["-fsanitize=thread"] + base[4:], capture_output=True).returncode != 0:
+        subprocess.run(base, check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "worker pool ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_shard_ranges_cover_and_balance():
     from stark_verifier_amd.sharding import shard_range
     for total in (0, 1, 7, 8, 1000, 1 << 20):
