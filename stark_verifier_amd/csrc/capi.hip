@@ -392,6 +392,17 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
         }
         a.W = W;
         set_quarter_root(a, w, (int)log_n);
+        if (plan->has_scale && log_n >= 3 && env_int("STARKHIP_FOLD_SCALE", 1)) {
+            // inverse: n^-1 rides on the last round (the kernel's last round has twiddles from 8 points on)
+            uint32_t* Ws;
+            if ((rc = make_table(ctx, plan.get(), w, n, 0, scale, &Ws, l29)) != STARK_OK) {
+                free_plan(plan.get());
+                return rc;
+            }
+            a.Wlast = Ws;
+            to_limbs29(scale, a.sc);
+            to_limbs29(hostfe::mul(scale, hostfe::pow_u64(hostfe::from_u64(2), 145)), a.sc2);
+        }
         plan->passes.push_back(p);
     } else {
         // n = n1 * m, m = n2 (* n3)
@@ -621,6 +632,7 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.ksh = 31;
             a.kmask = 0xFFFFFFFFu;
             if (ov) {  // polynomials are folded into the tile index here: lo * C + c
+                a.Wlast = nullptr;  // the override's table carries the plan's output factor
                 a.out = d_out + 8 * ov->out_poly * done;
                 a.outB = ov->out_poly << a.log_c;
                 a.outC = ov->out_poly;

@@ -278,7 +278,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         // the LDS reads so that both latencies overlap
         F29 tw1;
         const uint32_t e = ns_log > 0 ? (j & ((1u << ns_log) - 1u)) << (LOGQ - ns_log) : 0u;
-        if (ns_log > 0) tw1 = f29_load_raw(a.W + 12 * (size_t)e);
+        // the output factor of a single-pass inverse rides on the last round's twiddles when that round has any
+        const bool folded = last && ns_log > 0 && a.Wlast != nullptr;
+        const uint32_t* Wt = folded ? a.Wlast : a.W;
+        if (ns_log > 0) tw1 = f29_load_raw(Wt + 12 * (size_t)e);
         F29 x0, x1, x2, x3;
         if (first) {
             const Quad29 q = load_inputs(c, j, valid);
@@ -305,12 +308,13 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             // the three twiddled inputs come out of the multiplier tight; the untwiddled one is brought
             // back to 29-bit limbs by a carry pass. Each later twiddle is requested one multiplication
             // ahead of its use.
-            F29 tw2 = f29_load_raw(a.W + 12 * (size_t)(2 * e));
+            F29 tw2 = f29_load_raw(Wt + 12 * (size_t)(2 * e));
             x1 = f29_mul(x1, tw1);
-            F29 tw3 = f29_load_raw(a.W + 12 * (size_t)(3 * e));
+            F29 tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
             x2 = f29_mul(x2, tw2);
             x3 = f29_mul(x3, tw3);
-            x0 = f29_carry(x0);
+            if (folded) x0 = f29_mul_uniform2(x0, a.sc, a.sc2);
+            else x0 = f29_carry(x0);
         }
         // radix-4 butterfly, I = w_T^(T/4); every subtrahend is tight or a sum of two tight values
         F29 y0, y1, y2, y3;
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             else __syncthreads();  // the next round's inputs come from other wavefronts
             STAMP(1 + round);
         } else if (valid) {
-            if (!a.TW && a.has_scale) {
+            if (!a.TW && a.has_scale && !folded) {
                 Fe s;
 #pragma unroll
                 for (int l = 0; l < 8; l++) s.l[l] = a.scale[l];

@@ -214,6 +214,23 @@ def test_ntt_host_buffers_pipelined_equals_sequential(sv, log_n, batch, monkeypa
                 assert np.array_equal(a[i], want), (inverse, i)
 
 
+@pytest.mark.parametrize("log_n", [2, 3, 4, 5, 8, 11, 12])
+def test_ntt_single_pass_inverse_scale_on_the_last_round_or_after_it(sv, log_n, monkeypatch):
+    """Single-pass inverse transforms carry n^-1 on the last round's twiddles (default, from 8 points on) or apply it to
+    the outputs (STARKHIP_FOLD_SCALE=0): both equal the oracle's fft_inv, non-canonical inputs included."""
+    n, batch = 1 << log_n, 5
+    w = root_of_unity(log_n)
+    x = synth.field_elements(synth.SEED + 500 + log_n, batch * n).reshape(batch, n, 8)
+    x[1] = 0xFFFFFFFF  # every element 2^256 - 1
+    want = np.stack([oracle.fft_inv(oracle.ints_to_limbs([v % P for v in oracle.limbs_to_ints(x[b])]), w) for b in range(batch)])
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STARKHIP_FOLD_SCALE", mode)
+        ctx = sv.Context(0)  # the choice is made when a context builds the plan
+        got = sv.fft.ntt_batch(x, w, inverse=True, ctx=ctx)
+        ctx.close()
+        assert np.array_equal(got, want), mode
+
+
 def test_ntt_linearity_2p20(sv):
     log_n, n = 20, 1 << 20
     w = root_of_unity(log_n)
