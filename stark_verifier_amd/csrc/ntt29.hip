@@ -144,7 +144,9 @@ __device__ unsigned long long g_stamps[2][8192][16];
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int LOGT>
+// FOLD: the plan is a single-pass inverse whose output factor rides on the last round (NttPassArgs::Wlast, sc, sc2); a
+// separate instantiation, so that the forward and multi-pass kernels carry none of it
+template <int LOGT, bool FOLD>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     using G = TileGeom<LOGT>;
     constexpr uint32_t T = 1u << LOGT, Q = T / 4, LOGQ = LOGT - 2;
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         F29 tw1;
         const uint32_t e = ns_log > 0 ? (j & ((1u << ns_log) - 1u)) << (LOGQ - ns_log) : 0u;
         // the output factor of a single-pass inverse rides on the last round's twiddles when that round has any
-        const bool folded = last && ns_log > 0 && a.Wlast != nullptr;
+        const bool folded = FOLD && last && ns_log > 0;
         const uint32_t* Wt = folded ? a.Wlast : a.W;
         if (ns_log > 0) tw1 = f29_load_raw(Wt + 12 * (size_t)e);
         F29 x0, x1, x2, x3;
@@ -397,7 +399,7 @@ extern "C" int stark_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-template <int LOGT>
+template <int LOGT, bool FOLD>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
@@ -409,7 +411,7 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass_kernel<LOGT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass_kernel<LOGT, FOLD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev < 64) attr_set[dev].store(true, std::memory_order_release);
@@ -430,23 +432,29 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
             break;
         }
     if ((uint64_t)tiles * polys >= (1ull << 31)) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(ntt29_pass_kernel<LOGT>, dim3(tiles * polys), dim3(threads), lds, stream, b);
+    hipLaunchKernelGGL((ntt29_pass_kernel<LOGT, FOLD>), dim3(tiles * polys), dim3(threads), lds, stream, b);
     return hipGetLastError();
+}
+
+template <int LOGT>
+static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
+    if (LOGT >= 3 && a.Wlast != nullptr) return launch_one29<LOGT, (LOGT >= 3)>(a, tiles, polys, stream);
+    return launch_one29<LOGT, false>(a, tiles, polys, stream);
 }
 
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     switch (log_t) {
-        case 2: return launch_one29<2>(a, tiles, polys, stream);
-        case 3: return launch_one29<3>(a, tiles, polys, stream);
-        case 4: return launch_one29<4>(a, tiles, polys, stream);
-        case 5: return launch_one29<5>(a, tiles, polys, stream);
-        case 6: return launch_one29<6>(a, tiles, polys, stream);
-        case 7: return launch_one29<7>(a, tiles, polys, stream);
-        case 8: return launch_one29<8>(a, tiles, polys, stream);
-        case 9: return launch_one29<9>(a, tiles, polys, stream);
-        case 10: return launch_one29<10>(a, tiles, polys, stream);
-        case 11: return launch_one29<11>(a, tiles, polys, stream);
-        case 12: return launch_one29<12>(a, tiles, polys, stream);
+        case 2: return launch_either29<2>(a, tiles, polys, stream);
+        case 3: return launch_either29<3>(a, tiles, polys, stream);
+        case 4: return launch_either29<4>(a, tiles, polys, stream);
+        case 5: return launch_either29<5>(a, tiles, polys, stream);
+        case 6: return launch_either29<6>(a, tiles, polys, stream);
+        case 7: return launch_either29<7>(a, tiles, polys, stream);
+        case 8: return launch_either29<8>(a, tiles, polys, stream);
+        case 9: return launch_either29<9>(a, tiles, polys, stream);
+        case 10: return launch_either29<10>(a, tiles, polys, stream);
+        case 11: return launch_either29<11>(a, tiles, polys, stream);
+        case 12: return launch_either29<12>(a, tiles, polys, stream);
         default: return hipErrorInvalidValue;
     }
 }

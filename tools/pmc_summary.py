@@ -17,7 +17,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in args.dirs:
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void starkhip::", "")
+            # ntt29_pass_kernel<10, false> (the ordinary instantiation) is reported under its old name <10>
+            k = r["Kernel_Name"].split("(")[0].replace("void starkhip::", "").replace(", false>", ">")
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
 os.makedirs(os.path.join(root, "profiles", args.round), exist_ok=True)

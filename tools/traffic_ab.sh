@@ -19,7 +19,7 @@ for m in (0, 1):
         acc = collections.defaultdict(list)
         for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "pass_kernel<10>" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                if "pass_kernel<10" in r["Kernel_Name"] and r["Counter_Name"] == c:
                     acc[c].append(float(r["Counter_Value"]))
         v = acc[c]
         # launches alternate pass 1, pass 2
