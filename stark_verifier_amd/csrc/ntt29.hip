@@ -138,26 +138,44 @@ struct Quad29 {
 __device__ unsigned long long g_stamps[2][8192][16];
 #define STAMP(i)                                                                          \
     do {                                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[a.in_raw ? 1 : 0][blockIdx.x][i] = wall_clock64(); \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[in_raw ? 1 : 0][blockIdx.x][i] = wall_clock64(); \
     } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
-// FOLD: the plan is a single-pass inverse whose output factor rides on the last round (NttPassArgs::Wlast, sc, sc2); a
-// separate instantiation, so that the forward and multi-pass kernels carry none of it
-template <int LOGT, bool FOLD>
+// KIND: instantiations for the shapes that carry the load, with their flags known at compile time (fewer scalar
+// registers and branches: the general kernel sits at the scalar-register limit, and what spills costs every launch 1 %).
+//   0 general: every flag read from the arguments
+//   1 first pass of several from packed input: unpacked output, an inter-pass table, tile index fastest on both sides
+//   2 last pass of two from the tiled intermediate to packed output, no output table, tile index fastest on both sides
+//   3 general, and the plan is a single-pass inverse whose output factor rides on the last round (Wlast, sc, sc2)
+//   4 middle pass of three: unpacked on both sides, an inter-pass table, tile index fastest on both sides
+//   5 last pass of three: rows of the unpacked intermediate (element index fastest) to packed output, no output table
+// Kinds 1, 2, 4, 5 also know: no output factor, no split of the output index, every tile of the grid exists.
+constexpr int KIND_GENERAL = 0, KIND_FIRST = 1, KIND_LAST = 2, KIND_FOLD = 3, KIND_MID = 4, KIND_LAST3 = 5;
+
+template <int LOGT, int KIND>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
+    constexpr bool SPECIAL = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3;
+    constexpr bool FOLD = KIND == KIND_FOLD;
+    const bool in_raw = KIND == KIND_FIRST ? false : SPECIAL ? true : a.in_raw != 0;
+    const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.out_raw != 0;
+    const bool load_cfast = KIND == KIND_LAST3 ? false : SPECIAL ? true : a.load_cfast != 0;
+    const bool store_cfast = SPECIAL ? true : a.store_cfast != 0;
+    const bool has_tw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.TW != nullptr;
+    const bool has_scale = SPECIAL ? false : a.has_scale != 0;
     using G = TileGeom<LOGT>;
     constexpr uint32_t T = 1u << LOGT, Q = T / 4, LOGQ = LOGT - 2;
     constexpr int ROUNDS = (LOGT + 1) / 2;
     constexpr int LW = G::LW;
     extern __shared__ uint32_t lds[];
 
-    const uint32_t log_c = a.log_c, C = 1u << log_c;
+    // the special kinds also fix the tiles per workgroup at what the planner picks for this tile size (512 lanes)
+    const uint32_t log_c = SPECIAL ? (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0) : a.log_c, C = 1u << log_c;
     const uint32_t Tp = G::ROW + tile_pad29(log_c);
     const uint32_t tid = threadIdx.x;
-    const uint32_t in_w = a.in_raw ? RAW_W : 8u, out_w = a.out_raw ? RAW_W : 8u;
+    const uint32_t in_w = in_raw ? RAW_W : 8u, out_w = out_raw ? RAW_W : 8u;
     // Work item -> (tile, polynomial). Workgroups are dealt round-robin over the 8 XCDs, each with
     // its own L2. With the grouped order, the workgroups that share an L2 take 2^grp_log adjacent
     // tiles (whose strided 64..96-byte pieces complete each other's 128-byte lines) of every
@@ -201,7 +219,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         }
     };
     // the element-fastest edge order coincides with the local order when a tile is one wavefront or less
-    const bool load_is_local = !a.load_cfast && LW == 0;
+    const bool load_is_local = !load_cfast && LW == 0;
 
     // global -> registers for the lane's four inputs (first round; zeros for tiles past the end)
     auto load_inputs = [&](uint32_t c, uint32_t j, bool valid) -> Quad29 {
@@ -210,9 +228,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
             // offset of input j (in dwords): j * inS, or split at bit jsh of j
             auto jo = [&](uint32_t jj) -> uint64_t {
+                if (SPECIAL && KIND != KIND_LAST) return (uint64_t)in_w * ((uint64_t)jj * a.inS);
                 return (uint64_t)in_w * ((uint64_t)(jj >> a.jsh) * a.inS2 + (uint64_t)(jj & a.jmask) * a.inS);
             };
-            if (a.in_raw) {
+            if (in_raw) {
                 x0 = f29_load_mid(src + jo(j));
                 x1 = f29_load_mid(src + jo(j + Q));
                 x2 = f29_load_mid(src + jo(j + 2 * Q));
@@ -232,7 +251,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // Is the exchange after a round confined to each wavefront's own sub-image? (the round and the
     // next one both run in the local lane order, and Ns >= W keeps the low bits of j)
     auto exchange_is_local = [&](int round, bool local, uint32_t ns_now, uint32_t ns_next) {
-        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !(!a.store_cfast && LW == 0);
+        const bool next_last_edge = (round + 1 == ROUNDS - 1) && !(!store_cfast && LW == 0);
         return round != ROUNDS - 1 && local && ns_now >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
     };
 
@@ -242,8 +261,8 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     if (ODD) {
         // odd log2(T): one radix-2 level first, on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
         uint32_t c, j;
-        edge_map(a.load_cfast, c, j);
-        const bool valid = (uint64_t)lo * C + c < a.c_limit;
+        edge_map(load_cfast, c, j);
+        const bool valid = SPECIAL ? true : (uint64_t)lo * C + c < a.c_limit;
         const Quad29 q = load_inputs(c, j, valid);
         const F29 &x0 = q.a, &x1 = q.b, &x2 = q.c, &x3 = q.d;
         F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
@@ -263,18 +282,18 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         uint32_t c, j;
         if (first) {
             local = load_is_local;
-            edge_map(a.load_cfast, c, j);
+            edge_map(load_cfast, c, j);
         } else if (last) {
-            local = !a.store_cfast && LW == 0;
-            edge_map(a.store_cfast, c, j);
+            local = !store_cfast && LW == 0;
+            edge_map(store_cfast, c, j);
         } else if (ns_log >= (uint32_t)LW) {
             local = true;
             local_map(c, j);
         } else {
             local = false;
-            edge_map(a.load_cfast, c, j);
+            edge_map(load_cfast, c, j);
         }
-        const bool valid = (uint64_t)lo * C + c < a.c_limit;
+        const bool valid = SPECIAL ? true : (uint64_t)lo * C + c < a.c_limit;
 
         // the first of the round's three twiddles w_T^(r * (j mod Ns) * T/(4 Ns)) is requested before
         // the LDS reads so that both latencies overlap
@@ -331,7 +350,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             }
             // the inter-pass twiddles of the first two outputs are requested before the last multiplication
             // of the butterfly, the other two one multiplication ahead of their use
-            const bool tw_on = last && valid && a.TW != nullptr;
+            const bool tw_on = last && valid && has_tw;
             const uint32_t* tw = a.TW + 8 * (pidx * a.twP + hi * a.twA + lo * a.twB + c * a.twC);
             Fe t0, t1;
             if (tw_on) {
@@ -357,7 +376,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             else __syncthreads();  // the next round's inputs come from other wavefronts
             STAMP(1 + round);
         } else if (valid) {
-            if (!a.TW && a.has_scale && !folded) {
+            if (!has_tw && has_scale && !folded) {
                 Fe s;
 #pragma unroll
                 for (int l = 0; l < 8; l++) s.l[l] = a.scale[l];
@@ -370,9 +389,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             uint32_t* dst = a.out + out_w * ((uint64_t)pidx * a.outP + hi * a.outA + lo * a.outB + c * a.outC);
             // offset of output k (in dwords): k * outS, or split at bit ksh of k
             auto ko = [&](uint32_t k) -> uint64_t {
+                if (SPECIAL) return (uint64_t)out_w * ((uint64_t)k * a.outS);
                 return (uint64_t)out_w * ((uint64_t)(k >> a.ksh) * a.outS2 + (uint64_t)(k & a.kmask) * a.outS);
             };
-            if (a.out_raw) {
+            if (out_raw) {
                 f29_store_mid(dst + ko(j), y0);
                 f29_store_mid(dst + ko(j + Q), y1);
                 f29_store_mid(dst + ko(j + 2 * Q), y2);
@@ -399,7 +419,7 @@ extern "C" int stark_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-template <int LOGT, bool FOLD>
+template <int LOGT, int KIND>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
@@ -411,7 +431,7 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass_kernel<LOGT, FOLD>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass_kernel<LOGT, KIND>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev < 64) attr_set[dev].store(true, std::memory_order_release);
@@ -432,14 +452,27 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
             break;
         }
     if ((uint64_t)tiles * polys >= (1ull << 31)) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((ntt29_pass_kernel<LOGT, FOLD>), dim3(tiles * polys), dim3(threads), lds, stream, b);
+    hipLaunchKernelGGL((ntt29_pass_kernel<LOGT, KIND>), dim3(tiles * polys), dim3(threads), lds, stream, b);
     return hipGetLastError();
 }
 
 template <int LOGT>
 static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
-    if (LOGT >= 3 && a.Wlast != nullptr) return launch_one29<LOGT, (LOGT >= 3)>(a, tiles, polys, stream);
-    return launch_one29<LOGT, false>(a, tiles, polys, stream);
+    static const bool special = !(getenv("STARKHIP_SPECIALIZE") && atoi(getenv("STARKHIP_SPECIALIZE")) == 0);
+    if (LOGT >= 3 && a.Wlast != nullptr) return launch_one29<LOGT, (LOGT >= 3 ? KIND_FOLD : KIND_GENERAL)>(a, tiles, polys, stream);
+    if (special && LOGT >= 6 && !a.has_scale && a.store_cfast && a.ksh == 31 && a.c_limit == ~0ull &&
+        a.log_c == (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0)) {  // multi-pass plans in their usual shape
+        constexpr bool S = LOGT >= 6;
+        if (a.TW && a.load_cfast && !a.in_split && a.out_raw) {
+            if (!a.in_raw) return launch_one29<LOGT, (S ? KIND_FIRST : KIND_GENERAL)>(a, tiles, polys, stream);
+            return launch_one29<LOGT, (S ? KIND_MID : KIND_GENERAL)>(a, tiles, polys, stream);
+        }
+        if (!a.TW && a.in_raw && !a.out_raw) {
+            if (a.load_cfast && a.in_split) return launch_one29<LOGT, (S ? KIND_LAST : KIND_GENERAL)>(a, tiles, polys, stream);
+            if (!a.load_cfast && !a.in_split) return launch_one29<LOGT, (S ? KIND_LAST3 : KIND_GENERAL)>(a, tiles, polys, stream);
+        }
+    }
+    return launch_one29<LOGT, KIND_GENERAL>(a, tiles, polys, stream);
 }
 
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {

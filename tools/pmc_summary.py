@@ -3,7 +3,7 @@ and profiles/traffic.json (HBM bytes per unit of work of the two dominant kernel
 
     python tools/pmc_summary.py r01 gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s --ntt-polys 16 --merkle-n 1048576
 """
-import argparse, collections, csv, glob, json, os
+import argparse, collections, csv, glob, json, os, re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("round")
@@ -17,8 +17,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in args.dirs:
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            # ntt29_pass_kernel<10, false> (the ordinary instantiation) is reported under its old name <10>
-            k = r["Kernel_Name"].split("(")[0].replace("void starkhip::", "").replace(", false>", ">")
+            # the instantiations of the pass kernel for one tile size (<10, 1> first pass, <10, 2> last pass, ...) are
+            # reported together under the tile size alone, <10>: a launch of either moves one pass's bytes
+            k = re.sub(r"(ntt29_pass_kernel<\d+), \d+>", r"\1>", r["Kernel_Name"].split("(")[0].replace("void starkhip::", ""))
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
 os.makedirs(os.path.join(root, "profiles", args.round), exist_ok=True)
