@@ -400,8 +400,6 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
                 return rc;
             }
             a.Wlast = Ws;
-            to_limbs29(scale, a.sc);
-            to_limbs29(hostfe::mul(scale, hostfe::pow_u64(hostfe::from_u64(2), 145)), a.sc2);
         }
         plan->passes.push_back(p);
     } else {

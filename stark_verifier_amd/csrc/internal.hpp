@@ -75,10 +75,9 @@ struct NttPassArgs {
     uint32_t has_scale;
     uint32_t scale[8];  // multiplies every output when has_scale (single-pass inverse)
     // Single-pass inverse with at least one twiddled round: the factor rides on the last round instead of four more
-    // multiplications per lane: Wlast = W with every entry times the factor (the three twiddled inputs), and the fourth
-    // input is multiplied by the factor itself, given as 29-bit limbs sc and sc2 = factor * 2^145 (scalar operands).
+    // multiplications per lane: Wlast = W with every entry times the factor (the three twiddled inputs; entry 0, the
+    // factor itself, multiplies the fourth input).
     const uint32_t* Wlast;
-    uint32_t sc[9], sc2[9];
 };
 
 // W entries are 12 unpacked dwords

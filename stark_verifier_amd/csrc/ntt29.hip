@@ -149,22 +149,26 @@ __device__ unsigned long long g_stamps[2][8192][16];
 //   0 general: every flag read from the arguments
 //   1 first pass of several from packed input: unpacked output, an inter-pass table, tile index fastest on both sides
 //   2 last pass of two from the tiled intermediate to packed output, no output table, tile index fastest on both sides
-//   3 general, and the plan is a single-pass inverse whose output factor rides on the last round (Wlast, sc, sc2)
+//   3 single pass, inverse, the output factor riding on the last round (Wlast, sc, sc2); otherwise as 6
 //   4 middle pass of three: unpacked on both sides, an inter-pass table, tile index fastest on both sides
 //   5 last pass of three: rows of the unpacked intermediate (element index fastest) to packed output, no output table
-// Kinds 1, 2, 4, 5 also know: no output factor, no split of the output index, every tile of the grid exists.
-constexpr int KIND_GENERAL = 0, KIND_FIRST = 1, KIND_LAST = 2, KIND_FOLD = 3, KIND_MID = 4, KIND_LAST3 = 5;
+//   6 single pass, no output factor: packed on both sides, element index fastest, no table
+// Kinds 1, 2, 4, 5 (the passes of multi-pass plans) also know that every tile of the grid exists and how many tiles a
+// workgroup takes; all but 0 know that the output index is not split.
+constexpr int KIND_GENERAL = 0, KIND_FIRST = 1, KIND_LAST = 2, KIND_FOLD = 3, KIND_MID = 4, KIND_LAST3 = 5, KIND_SINGLE = 6;
 
 template <int LOGT, int KIND>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
-    constexpr bool SPECIAL = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3;
+    constexpr bool MULTI = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3;
+    constexpr bool ONE = KIND == KIND_FOLD || KIND == KIND_SINGLE;
+    constexpr bool SPECIAL = MULTI || ONE;
     constexpr bool FOLD = KIND == KIND_FOLD;
-    const bool in_raw = KIND == KIND_FIRST ? false : SPECIAL ? true : a.in_raw != 0;
+    const bool in_raw = (KIND == KIND_FIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
     const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.out_raw != 0;
-    const bool load_cfast = KIND == KIND_LAST3 ? false : SPECIAL ? true : a.load_cfast != 0;
-    const bool store_cfast = SPECIAL ? true : a.store_cfast != 0;
+    const bool load_cfast = (KIND == KIND_LAST3 || ONE) ? false : MULTI ? true : a.load_cfast != 0;
+    const bool store_cfast = ONE ? false : MULTI ? true : a.store_cfast != 0;
     const bool has_tw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.TW != nullptr;
-    const bool has_scale = SPECIAL ? false : a.has_scale != 0;
+    const bool has_scale = FOLD ? true : SPECIAL ? false : a.has_scale != 0;
     using G = TileGeom<LOGT>;
     constexpr uint32_t T = 1u << LOGT, Q = T / 4, LOGQ = LOGT - 2;
     constexpr int ROUNDS = (LOGT + 1) / 2;
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     extern __shared__ uint32_t lds[];
 
     // the special kinds also fix the tiles per workgroup at what the planner picks for this tile size (512 lanes)
-    const uint32_t log_c = SPECIAL ? (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0) : a.log_c, C = 1u << log_c;
+    const uint32_t log_c = MULTI ? (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0) : a.log_c, C = 1u << log_c;
     const uint32_t Tp = G::ROW + tile_pad29(log_c);
     const uint32_t tid = threadIdx.x;
     const uint32_t in_w = in_raw ? RAW_W : 8u, out_w = out_raw ? RAW_W : 8u;
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         // odd log2(T): one radix-2 level first, on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
         uint32_t c, j;
         edge_map(load_cfast, c, j);
-        const bool valid = SPECIAL ? true : (uint64_t)lo * C + c < a.c_limit;
+        const bool valid = MULTI ? true : (uint64_t)lo * C + c < a.c_limit;
         const Quad29 q = load_inputs(c, j, valid);
         const F29 &x0 = q.a, &x1 = q.b, &x2 = q.c, &x3 = q.d;
         F29 y0 = f29_add(x0, x2), y1 = f29_sub(x0, x2), y2 = f29_add(x1, x3), y3 = f29_sub(x1, x3);
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             local = false;
             edge_map(load_cfast, c, j);
         }
-        const bool valid = SPECIAL ? true : (uint64_t)lo * C + c < a.c_limit;
+        const bool valid = MULTI ? true : (uint64_t)lo * C + c < a.c_limit;
 
         // the first of the round's three twiddles w_T^(r * (j mod Ns) * T/(4 Ns)) is requested before
         // the LDS reads so that both latencies overlap
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             F29 tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
             x2 = f29_mul(x2, tw2);
             x3 = f29_mul(x3, tw3);
-            if (folded) x0 = f29_mul_uniform2(x0, a.sc, a.sc2);
+            if (folded) x0 = f29_mul(x0, f29_load_raw(Wt));  // entry 0 of the scaled table is the factor itself
             else x0 = f29_carry(x0);
         }
         // radix-4 butterfly, I = w_T^(T/4); every subtrahend is tight or a sum of two tight values
@@ -459,20 +463,28 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
 template <int LOGT>
 static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     static const bool special = !(getenv("STARKHIP_SPECIALIZE") && atoi(getenv("STARKHIP_SPECIALIZE")) == 0);
-    if (LOGT >= 3 && a.Wlast != nullptr) return launch_one29<LOGT, (LOGT >= 3 ? KIND_FOLD : KIND_GENERAL)>(a, tiles, polys, stream);
+    const bool plain_index = a.ksh == 31 && !a.in_split;
+    // single pass: packed on both sides, element index fastest, no table
+    if (LOGT >= 3 && plain_index && !a.in_raw && !a.out_raw && !a.TW && !a.load_cfast && !a.store_cfast) {
+        constexpr bool S = LOGT >= 3;
+        if (a.Wlast != nullptr && a.has_scale) return launch_one29<LOGT, (S ? KIND_FOLD : KIND_GENERAL)>(a, tiles, polys, stream);
+        if (special && !a.has_scale) return launch_one29<LOGT, (S ? KIND_SINGLE : KIND_GENERAL)>(a, tiles, polys, stream);
+    }
+    NttPassArgs g = a;
+    g.Wlast = nullptr;  // only the kind above carries the output factor on its last round
     if (special && LOGT >= 6 && !a.has_scale && a.store_cfast && a.ksh == 31 && a.c_limit == ~0ull &&
         a.log_c == (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0)) {  // multi-pass plans in their usual shape
         constexpr bool S = LOGT >= 6;
         if (a.TW && a.load_cfast && !a.in_split && a.out_raw) {
-            if (!a.in_raw) return launch_one29<LOGT, (S ? KIND_FIRST : KIND_GENERAL)>(a, tiles, polys, stream);
-            return launch_one29<LOGT, (S ? KIND_MID : KIND_GENERAL)>(a, tiles, polys, stream);
+            if (!a.in_raw) return launch_one29<LOGT, (S ? KIND_FIRST : KIND_GENERAL)>(g, tiles, polys, stream);
+            return launch_one29<LOGT, (S ? KIND_MID : KIND_GENERAL)>(g, tiles, polys, stream);
         }
         if (!a.TW && a.in_raw && !a.out_raw) {
-            if (a.load_cfast && a.in_split) return launch_one29<LOGT, (S ? KIND_LAST : KIND_GENERAL)>(a, tiles, polys, stream);
-            if (!a.load_cfast && !a.in_split) return launch_one29<LOGT, (S ? KIND_LAST3 : KIND_GENERAL)>(a, tiles, polys, stream);
+            if (a.load_cfast && a.in_split) return launch_one29<LOGT, (S ? KIND_LAST : KIND_GENERAL)>(g, tiles, polys, stream);
+            if (!a.load_cfast && !a.in_split) return launch_one29<LOGT, (S ? KIND_LAST3 : KIND_GENERAL)>(g, tiles, polys, stream);
         }
     }
-    return launch_one29<LOGT, KIND_GENERAL>(a, tiles, polys, stream);
+    return launch_one29<LOGT, KIND_GENERAL>(g, tiles, polys, stream);
 }
 
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
