@@ -148,7 +148,8 @@ __device__ unsigned long long g_stamps[2][8192][16];
 // registers and branches: the general kernel sits at the scalar-register limit, and what spills costs every launch 1 %).
 //   0 general: every flag read from the arguments
 //   1 first pass of several from packed input: unpacked output, an inter-pass table, tile index fastest on both sides
-//   2 last pass of two from the tiled intermediate to packed output, no output table, tile index fastest on both sides
+//   2 last pass from an unpacked intermediate (tiled or not) to packed output, no output table, tile index fastest on
+//     both sides
 //   3 single pass, inverse, the output factor riding on the last round (Wlast, sc, sc2); otherwise as 6
 //   4 middle pass of three: unpacked on both sides, an inter-pass table, tile index fastest on both sides
 //   5 last pass of three: rows of the unpacked intermediate (element index fastest) to packed output, no output table
@@ -356,21 +357,35 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             // of the butterfly, the other two one multiplication ahead of their use
             const bool tw_on = last && valid && has_tw;
             const uint32_t* tw = a.TW + 8 * (pidx * a.twP + hi * a.twA + lo * a.twB + c * a.twC);
+            // How far ahead the four table entries are requested is a trade between latency and registers: two ahead
+            // everywhere except at 1024-point tiles, where that costs a spilled register (one ahead there: +1.4 %;
+            // one ahead at 256-point tiles: -2.4 %)
+            constexpr bool TW_ONE_AHEAD = LOGT == 10;
             Fe t0, t1;
             if (tw_on) {
                 t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
-                t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
+                if (!TW_ONE_AHEAD) t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
             }
             F29 a3 = f29_mul_uniform2(f29_sub(x1, x3), a.iq, a.iq2);
             y1 = f29_add(a1, a3);
             y3 = f29_sub(a1, a3);
             if (tw_on) {
-                Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
-                y0 = f29_mul(y0, f29_from_fe(t0));
-                Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
-                y1 = f29_mul(y1, f29_from_fe(t1));
-                y2 = f29_mul(y2, f29_from_fe(t2));
-                y3 = f29_mul(y3, f29_from_fe(t3));
+                if (TW_ONE_AHEAD) {
+                    t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
+                    y0 = f29_mul(y0, f29_from_fe(t0));
+                    const Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
+                    y1 = f29_mul(y1, f29_from_fe(t1));
+                    const Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
+                    y2 = f29_mul(y2, f29_from_fe(t2));
+                    y3 = f29_mul(y3, f29_from_fe(t3));
+                } else {
+                    const Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
+                    y0 = f29_mul(y0, f29_from_fe(t0));
+                    const Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
+                    y1 = f29_mul(y1, f29_from_fe(t1));
+                    y2 = f29_mul(y2, f29_from_fe(t2));
+                    y3 = f29_mul(y3, f29_from_fe(t3));
+                }
             }
         }
         if (!last) {
@@ -464,14 +479,18 @@ template <int LOGT>
 static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     static const bool special = !(getenv("STARKHIP_SPECIALIZE") && atoi(getenv("STARKHIP_SPECIALIZE")) == 0);
     const bool plain_index = a.ksh == 31 && !a.in_split;
-    // single pass: packed on both sides, element index fastest, no table
-    if (LOGT >= 3 && plain_index && !a.in_raw && !a.out_raw && !a.TW && !a.load_cfast && !a.store_cfast) {
-        constexpr bool S = LOGT >= 3;
-        if (a.Wlast != nullptr && a.has_scale) return launch_one29<LOGT, (S ? KIND_FOLD : KIND_GENERAL)>(a, tiles, polys, stream);
-        if (special && !a.has_scale) return launch_one29<LOGT, (S ? KIND_SINGLE : KIND_GENERAL)>(a, tiles, polys, stream);
-    }
     NttPassArgs g = a;
-    g.Wlast = nullptr;  // only the kind above carries the output factor on its last round
+    g.Wlast = nullptr;  // only KIND_FOLD carries the output factor on its last round
+    // single pass: packed on both sides, element index fastest
+    if (LOGT >= 3 && !a.in_split && !a.in_raw && !a.out_raw && !a.load_cfast && !a.store_cfast) {
+        constexpr bool S = LOGT >= 3;
+        if (!a.TW && plain_index) {
+            if (a.Wlast != nullptr && a.has_scale) return launch_one29<LOGT, (S ? KIND_FOLD : KIND_GENERAL)>(a, tiles, polys, stream);
+            if (special && !a.has_scale) return launch_one29<LOGT, (S ? KIND_SINGLE : KIND_GENERAL)>(g, tiles, polys, stream);
+        }
+        // (with an output table and a split output index, stage A of a sharded transform: its own instantiation was 2 %
+        // slower than the general kernel at 2^12 points, 128 registers against 123)
+    }
     if (special && LOGT >= 6 && !a.has_scale && a.store_cfast && a.ksh == 31 && a.c_limit == ~0ull &&
         a.log_c == (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0)) {  // multi-pass plans in their usual shape
         constexpr bool S = LOGT >= 6;
@@ -480,7 +499,7 @@ static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned
             return launch_one29<LOGT, (S ? KIND_MID : KIND_GENERAL)>(g, tiles, polys, stream);
         }
         if (!a.TW && a.in_raw && !a.out_raw) {
-            if (a.load_cfast && a.in_split) return launch_one29<LOGT, (S ? KIND_LAST : KIND_GENERAL)>(g, tiles, polys, stream);
+            if (a.load_cfast) return launch_one29<LOGT, (S ? KIND_LAST : KIND_GENERAL)>(g, tiles, polys, stream);
             if (!a.load_cfast && !a.in_split) return launch_one29<LOGT, (S ? KIND_LAST3 : KIND_GENERAL)>(g, tiles, polys, stream);
         }
     }
