@@ -150,7 +150,7 @@ __device__ unsigned long long g_stamps[2][8192][16];
 //   1 first pass of several from packed input: unpacked output, an inter-pass table, tile index fastest on both sides
 //   2 last pass from an unpacked intermediate (tiled or not) to packed output, no output table, tile index fastest on
 //     both sides
-//   3 single pass, inverse, the output factor riding on the last round (Wlast, sc, sc2); otherwise as 6
+//   3 single pass, inverse, the output factor riding on the last round (Wlast); otherwise as 6
 //   4 middle pass of three: unpacked on both sides, an inter-pass table, tile index fastest on both sides
 //   5 last pass of three: rows of the unpacked intermediate (element index fastest) to packed output, no output table
 //   6 single pass, no output factor: packed on both sides, element index fastest, no table
