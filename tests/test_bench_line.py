@@ -40,3 +40,48 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert sh["equals_single_gpu_call"] is True and sh["value"] > 0 and sh["all_to_all_bytes_sent_per_gpu"] == 0
     for k in ("stage_a_ms", "all_to_all_ms", "stage_c_ms", "single_gpu_call_ms_per_step", "contiguous_in_and_out_ms_per_step"):
         assert k in sh, k
+
+
+GUARD_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, %r)
+import bench
+g = bench.RegionGuard(int(sys.argv[1]), 2, {"metric": "m", "value": 1.0} if sys.argv[1] == "0" else None)
+g.arm("first", 30.0)
+g.disarm()                      # a region that finished: its timer must never act
+if sys.argv[2] == "hang":
+    g.arm("sharded_ntt", 0.5)
+    time.sleep(20)              # stands for a collective that never completes
+    print("not reached")
+elif sys.argv[2] == "alone":
+    g.arm("batch_verify", 30.0)
+    g.failed_alone("batch_verify", "RuntimeError: only this rank")
+    print("not reached")
+else:
+    g.arm("sharded_ntt", 30.0)
+    g.disarm()
+    g.print_line()
+    g.print_line()              # the line is printed once
+"""
+
+
+@pytest.mark.parametrize("rank,mode", [(0, "hang"), (1, "hang"), (0, "alone"), (1, "alone"), (0, "fine")])
+def test_region_guard_keeps_the_line_when_a_later_region_does_not_finish(rank, mode):
+    """bench.py's regions after the headline run under a timer: when one does not finish (or a rank fails alone in a
+    region with barriers), rank 0 prints the line it holds with an error record for that region, other ranks print
+    nothing, and every rank leaves with status 0 (anything else makes the launcher stop rank 0 before it has printed)."""
+    r = subprocess.run([sys.executable, "-c", GUARD_SCRIPT % ROOT, str(rank), mode], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    if rank != 0:
+        assert lines == []
+        return
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["metric"] == "m" and d["value"] == 1.0 and "first" not in d
+    if mode == "hang":
+        assert "did not finish" in d["sharded_ntt"]["error"]
+    elif mode == "alone":
+        assert d["batch_verify"]["error"] == "RuntimeError: only this rank"
+    else:
+        assert "sharded_ntt" not in d
