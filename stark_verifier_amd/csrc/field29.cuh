@@ -105,72 +105,105 @@ __device__ __forceinline__ F29 f29_sub2(const F29& a, const F29& b) {
 
 // acc += sum of N products, as one strictly serial v_mad_u64_u32 chain (the compiler would
 // otherwise start a second accumulator per column and pay a 64-bit add to merge it).
+// F29_M0 opens a chain at zero (it writes the accumulator without reading it).
 #define F29_M(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\t"
+#define F29_M0(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", 0\n\t"
 #define F29_P(x, y) "v"(x), "v"(y)
 #define F29_K(x, c) "v"(x), "s"(c)
 #define F29_PS(x, y) "v"(x), "s"(y)
+// Leaving a column. F29_NEXT: its limb is the low 29 bits, the rest starts the next column (one v_and, one 64-bit
+// shift). F29_WIDE: its limb is the whole low register, and the high register times 8 starts the next column
+// (acc = lo + 2^32 hi = lo + 2^29 * 8 hi), set by one multiply-add of its own with the constants 8 and 0: no
+// v_and, and a multiply-add in place of the shift. Wide limbs are below 2^32 instead of 2^29, which is fine wherever
+// the limb is only a multiplier operand or an addend of a later 64-bit sum: the high limbs th[] (a column then holds
+// at most nine products below 3 * 2^59 each plus th * FOLD0 < 2^61 plus th * FOLD1 < 2^49: below 2^64) and the low
+// limbs 0..2, which the second fold masks anyway.
+#define F29_NEXT(dst)               \
+    dst = (uint32_t)acc & F29_MASK; \
+    acc >>= 29;
+#define F29_WIDE(dst)                                                                             \
+    dst = (uint32_t)acc;                                                                          \
+    hi = (uint32_t)(acc >> 32);                                                                   \
+    asm("v_mad_u64_u32 %0, vcc, %1, 8, 0" : "=v"(acc) : "v"(hi) : "vcc"); /* may reuse acc's registers */
+
+#define F29_STEP_HI(dst)                 \
+    if constexpr ((WIDE & 1) != 0) {     \
+        F29_WIDE(dst)                    \
+    } else {                             \
+        F29_NEXT(dst)                    \
+    }
+#define F29_STEP_LO(dst)                 \
+    if constexpr ((WIDE & 2) != 0) {     \
+        F29_WIDE(dst)                    \
+    } else {                             \
+        F29_NEXT(dst)                    \
+    }
 
 // a * b mod p (not fully reduced): a lazy (limbs < 3*2^30), b tight. Returns a tight value.
+// WIDE: bit 0 = wide limbs leaving the high columns, bit 1 = leaving low columns 0..2. The wide form saves a tenth of
+// the instructions but keeps a few more registers alive (a wide limb stays in the low half of the pair its column
+// ended in): bit 0 costs about five registers, bit 1 none, so bit 0 is for kernels with registers to spare.
+template <int WIDE = 2>
 __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
     const uint32_t* a = x.l;
     const uint32_t* b = y.l;
     const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1;
-    // columns 9..16 first: their 29-bit limbs th[0..8] sit at 2^261 * 2^(29 k)
+    // columns 9..16 first: their limbs th[0..8] sit at 2^261 * 2^(29 k)
+    [[maybe_unused]] uint32_t hi;
     uint32_t th[9];
-    uint64_t acc = 0;
-#define F29_NEXT(dst)                       \
-    dst = (uint32_t)acc & F29_MASK;         \
-    acc >>= 29;
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
-        : "+v"(acc)
+    uint64_t acc;
+    asm(F29_M0(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16)
+        : "=&v"(acc)
         : F29_P(a[1], b[8]), F29_P(a[2], b[7]), F29_P(a[3], b[6]), F29_P(a[4], b[5]), F29_P(a[5], b[4]),
           F29_P(a[6], b[3]), F29_P(a[7], b[2]), F29_P(a[8], b[1])
         : "vcc");
-    F29_NEXT(th[0])
+    F29_STEP_HI(th[0])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14)
         : "+v"(acc)
         : F29_P(a[2], b[8]), F29_P(a[3], b[7]), F29_P(a[4], b[6]), F29_P(a[5], b[5]), F29_P(a[6], b[4]),
           F29_P(a[7], b[3]), F29_P(a[8], b[2])
         : "vcc");
-    F29_NEXT(th[1])
+    F29_STEP_HI(th[1])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
         : "+v"(acc)
         : F29_P(a[3], b[8]), F29_P(a[4], b[7]), F29_P(a[5], b[6]), F29_P(a[6], b[5]), F29_P(a[7], b[4]),
           F29_P(a[8], b[3])
         : "vcc");
-    F29_NEXT(th[2])
+    F29_STEP_HI(th[2])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
         : "+v"(acc)
         : F29_P(a[4], b[8]), F29_P(a[5], b[7]), F29_P(a[6], b[6]), F29_P(a[7], b[5]), F29_P(a[8], b[4])
         : "vcc");
-    F29_NEXT(th[3])
+    F29_STEP_HI(th[3])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
         : "+v"(acc)
         : F29_P(a[5], b[8]), F29_P(a[6], b[7]), F29_P(a[7], b[6]), F29_P(a[8], b[5])
         : "vcc");
-    F29_NEXT(th[4])
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : F29_P(a[6], b[8]), F29_P(a[7], b[7]), F29_P(a[8], b[6]) : "vcc");
-    F29_NEXT(th[5])
+    F29_STEP_HI(th[4])
+    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6)
+        : "+v"(acc)
+        : F29_P(a[6], b[8]), F29_P(a[7], b[7]), F29_P(a[8], b[6])
+        : "vcc");
+    F29_STEP_HI(th[5])
     asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_P(a[7], b[8]), F29_P(a[8], b[7]) : "vcc");
-    F29_NEXT(th[6])
+    F29_STEP_HI(th[6])
     asm(F29_M(1, 2) : "+v"(acc) : F29_P(a[8], b[8]) : "vcc");
-    F29_NEXT(th[7])
-    th[8] = (uint32_t)acc;  // below 2^27
+    F29_STEP_HI(th[7])
+    th[8] = (uint32_t)acc;  // what the last column (below 2^61) hands on: below 2^32
     // columns 0..8 with the high limbs folded in: 2^261 * t == (FOLD1 * 2^29 + FOLD0) * t
     uint32_t r[9];
-    acc = 0;
-    asm(F29_M(1, 2) F29_M(3, 4) : "+v"(acc) : F29_P(a[0], b[0]), F29_K(th[0], f0) : "vcc");
-    F29_NEXT(r[0])
+    asm(F29_M0(1, 2) F29_M(3, 4) : "=&v"(acc) : F29_P(a[0], b[0]), F29_K(th[0], f0) : "vcc");
+    F29_STEP_LO(r[0])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8)
         : "+v"(acc)
         : F29_P(a[0], b[1]), F29_P(a[1], b[0]), F29_K(th[1], f0), F29_K(th[0], f1)
         : "vcc");
-    F29_NEXT(r[1])
+    F29_STEP_LO(r[1])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10)
         : "+v"(acc)
         : F29_P(a[0], b[2]), F29_P(a[1], b[1]), F29_P(a[2], b[0]), F29_K(th[2], f0), F29_K(th[1], f1)
         : "vcc");
-    F29_NEXT(r[2])
+    F29_STEP_LO(r[2])
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12)
         : "+v"(acc)
         : F29_P(a[0], b[3]), F29_P(a[1], b[2]), F29_P(a[2], b[1]), F29_P(a[3], b[0]), F29_K(th[3], f0),
@@ -211,7 +244,6 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
           F29_K(th[7], f1)
         : "vcc");
     F29_NEXT(r[8])
-#undef F29_NEXT
     acc = mad64(th[8], F29_FOLD1, acc);  // what remains at 2^261: below 2^45
     // second fold at 2^256: top = everything above bit 256 = (acc << 5) | (r[8] >> 24)
     uint64_t top = (acc << 5) | (uint64_t)(r[8] >> 24);
@@ -243,31 +275,28 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
 // The body is a macro over the operand-pair constraint so that the register-only benchmark (kernbench.hip) can also
 // build the variant with per-lane second operands, which the transform does not use: inside the pass kernel the
 // second table load per twiddle costs more than the 18 multiply-adds it saves.
-#define F29_NEXT(dst)                       \
-    dst = (uint32_t)acc & F29_MASK;         \
-    acc >>= 29;
 #define F29_MUL_SPLIT_BODY(PAIR) \
     const uint32_t* a = x.l; \
     const uint32_t f0 = F29_FOLD0, f1 = F29_FOLD1; \
+    [[maybe_unused]] uint32_t hi; \
     uint32_t th[5]; \
-    uint64_t acc = 0; \
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) : "+v"(acc) : PAIR(a[1], b[8]), PAIR(a[2], b[7]), PAIR(a[3], b[6]), PAIR(a[4], b[5]), PAIR(a[6], c[8]), PAIR(a[7], c[7]), PAIR(a[8], c[6]) : "vcc"); \
-    F29_NEXT(th[0]) \
+    uint64_t acc; \
+    asm(F29_M0(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) : "=&v"(acc) : PAIR(a[1], b[8]), PAIR(a[2], b[7]), PAIR(a[3], b[6]), PAIR(a[4], b[5]), PAIR(a[6], c[8]), PAIR(a[7], c[7]), PAIR(a[8], c[6]) : "vcc"); \
+    F29_STEP_HI(th[0]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) : "+v"(acc) : PAIR(a[2], b[8]), PAIR(a[3], b[7]), PAIR(a[4], b[6]), PAIR(a[7], c[8]), PAIR(a[8], c[7]) : "vcc"); \
-    F29_NEXT(th[1]) \
+    F29_STEP_HI(th[1]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : PAIR(a[3], b[8]), PAIR(a[4], b[7]), PAIR(a[8], c[8]) : "vcc"); \
-    F29_NEXT(th[2]) \
+    F29_STEP_HI(th[2]) \
     asm(F29_M(1, 2) : "+v"(acc) : PAIR(a[4], b[8]) : "vcc"); \
-    F29_NEXT(th[3]) \
+    F29_STEP_HI(th[3]) \
     th[4] = (uint32_t)acc; \
     uint32_t r[9]; \
-    acc = 0; \
-    asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) : "+v"(acc) : PAIR(a[0], b[0]), PAIR(a[5], c[0]), F29_K(th[0], f0) : "vcc"); \
-    F29_NEXT(r[0]) \
+    asm(F29_M0(1, 2) F29_M(3, 4) F29_M(5, 6) : "=&v"(acc) : PAIR(a[0], b[0]), PAIR(a[5], c[0]), F29_K(th[0], f0) : "vcc"); \
+    F29_STEP_LO(r[0]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) : "+v"(acc) : PAIR(a[0], b[1]), PAIR(a[1], b[0]), PAIR(a[5], c[1]), PAIR(a[6], c[0]), F29_K(th[1], f0), F29_K(th[0], f1) : "vcc"); \
-    F29_NEXT(r[1]) \
+    F29_STEP_LO(r[1]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) : "+v"(acc) : PAIR(a[0], b[2]), PAIR(a[1], b[1]), PAIR(a[2], b[0]), PAIR(a[5], c[2]), PAIR(a[6], c[1]), PAIR(a[7], c[0]), F29_K(th[2], f0), F29_K(th[1], f1) : "vcc"); \
-    F29_NEXT(r[2]) \
+    F29_STEP_LO(r[2]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) : "+v"(acc) : PAIR(a[0], b[3]), PAIR(a[1], b[2]), PAIR(a[2], b[1]), PAIR(a[3], b[0]), PAIR(a[5], c[3]), PAIR(a[6], c[2]), PAIR(a[7], c[1]), PAIR(a[8], c[0]), F29_K(th[3], f0), F29_K(th[2], f1) : "vcc"); \
     F29_NEXT(r[3]) \
     asm(F29_M(1, 2) F29_M(3, 4) F29_M(5, 6) F29_M(7, 8) F29_M(9, 10) F29_M(11, 12) F29_M(13, 14) F29_M(15, 16) F29_M(17, 18) F29_M(19, 20) F29_M(21, 22) : "+v"(acc) : PAIR(a[0], b[4]), PAIR(a[1], b[3]), PAIR(a[2], b[2]), PAIR(a[3], b[1]), PAIR(a[4], b[0]), PAIR(a[5], c[4]), PAIR(a[6], c[3]), PAIR(a[7], c[2]), PAIR(a[8], c[1]), F29_K(th[4], f0), F29_K(th[3], f1) : "vcc"); \
@@ -298,11 +327,12 @@ __device__ __forceinline__ F29 f29_mul(const F29& x, const F29& y) {
     for (int i = 4; i < 9; i++) o.l[i] = r[i]; \
     return o;
 
+template <int WIDE = 2>
 __device__ __forceinline__ F29 f29_mul_uniform2(const F29& x, const uint32_t (&b)[9], const uint32_t (&c)[9]) {
     F29_MUL_SPLIT_BODY(F29_PS)
 }
 
-#undef F29_NEXT
+// (the F29_ macros stay defined: kernbench.hip builds the split body with per-lane operands)
 
 // Lazy -> tight without a multiplication: one carry pass that also folds what lies above bit 256 (taken
 // from limb 8 before the carries below it arrive): e * 2^256 == e * (2808 * 2^29 - 1), e < 2^8, entered as

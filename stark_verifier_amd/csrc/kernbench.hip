@@ -84,12 +84,14 @@ __global__ void __launch_bounds__(256) k_butterfly(Stamp* st, uint32_t* sink, ui
     if (acc == 0x1234567) sink[0] = acc;
 }
 
+// W: the multiplier's limb form (0 narrow everywhere, 2 wide in low columns 0..2, 3 wide in the high columns too)
+template <int W>
 __global__ void __launch_bounds__(256) k_femul29(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 a = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), b = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
     unsigned long long c0, r0;
     stamp_begin(c0, r0);
 #pragma unroll 1
-    for (int it = 0; it < ITERS; it++) a = f29_mul(a, b);
+    for (int it = 0; it < ITERS; it++) a = f29_mul<W>(a, b);
     stamp_end(st, c0, r0);
     uint32_t acc = 0;
     for (int i = 0; i < 9; i++) acc ^= a.l[i];
@@ -97,24 +99,22 @@ __global__ void __launch_bounds__(256) k_femul29(Stamp* st, uint32_t* sink, uint
 }
 
 // per-lane operands of the split product: y = b, y2 = b * 2^145 mod p (benchmark only, see field29.cuh)
-#define F29_NEXT(dst)                       \
-    dst = (uint32_t)acc & F29_MASK;         \
-    acc >>= 29;
+template <int WIDE = 3>
 __device__ __forceinline__ F29 f29_mul_split(const F29& x, const F29& y, const F29& y2) {
     const uint32_t* b = y.l;
     const uint32_t* c = y2.l;
     F29_MUL_SPLIT_BODY(F29_P)
 }
-#undef F29_NEXT
 
 // the split product with per-lane second operands (b, b * 2^145): 85 multiply-adds
+template <int W>
 __global__ void __launch_bounds__(256) k_femul29_split(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 a = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), b = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
     F29 c = f29_from_fe(fe_canon(seed_fe(s * 7 + blockIdx.x)));
     unsigned long long c0, r0;
     stamp_begin(c0, r0);
 #pragma unroll 1
-    for (int it = 0; it < ITERS; it++) a = f29_mul_split(a, b, c);
+    for (int it = 0; it < ITERS; it++) a = f29_mul_split<W>(a, b, c);
     stamp_end(st, c0, r0);
     uint32_t acc = 0;
     for (int i = 0; i < 9; i++) acc ^= a.l[i];
@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) k_femul29_split(Stamp* st, uint32_t* sink
 }
 
 // the same with the second operands in scalar registers (a wave-uniform constant)
+template <int W>
 __global__ void __launch_bounds__(256) k_femul29_uniform(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 a = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x)));
     uint32_t b[9], c[9];
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) k_femul29_uniform(Stamp* st, uint32_t* si
     unsigned long long c0, r0;
     stamp_begin(c0, r0);
 #pragma unroll 1
-    for (int it = 0; it < ITERS; it++) a = f29_mul_uniform2(a, b, c);
+    for (int it = 0; it < ITERS; it++) a = f29_mul_uniform2<W>(a, b, c);
     stamp_end(st, c0, r0);
     uint32_t acc = 0;
     for (int i = 0; i < 9; i++) acc ^= a.l[i];
@@ -400,6 +401,7 @@ __global__ void __launch_bounds__(256) k_prod_check(uint32_t* out, uint32_t s) {
     for (int i = 0; i < 17; i++) out[17 * (size_t)t + i] = w[i];
 }
 
+template <int W>
 __global__ void __launch_bounds__(256) k_butterfly29(Stamp* st, uint32_t* sink, uint32_t s) {
     F29 x = f29_from_fe(fe_canon(seed_fe(s + threadIdx.x))), y = f29_from_fe(fe_canon(seed_fe(s * 5 + threadIdx.x)));
     F29 w = f29_from_fe(fe_canon(seed_fe(s * 3 + blockIdx.x)));
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(256) k_butterfly29(Stamp* st, uint32_t* sink, 
     stamp_begin(c0, r0);
 #pragma unroll 1
     for (int it = 0; it < ITERS; it++) {
-        F29 t = f29_mul(y, w);
+        F29 t = f29_mul<W>(y, w);
         F29 u = f29_add(x, t);
         y = f29_sub(x, t);
         x = f29_carry(u);
@@ -479,10 +481,15 @@ int main(int argc, char** argv) {
     printf("waves/SIMD requested %d (256-thread blocks, %d blocks)\n", wps, blocks);
     run("fe_mul", k_femul, blocks, d_st, h_st, d_sink);
     run("butterfly", k_butterfly, blocks, d_st, h_st, d_sink);
-    run("f29_mul", k_femul29, blocks, d_st, h_st, d_sink);
-    run("f29_mul_split", k_femul29_split, blocks, d_st, h_st, d_sink);
-    run("f29_mul_unif2", k_femul29_uniform, blocks, d_st, h_st, d_sink);
-    run("butterfly29", k_butterfly29, blocks, d_st, h_st, d_sink);
+    run("f29_mul narrow", k_femul29<0>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w2", k_femul29<2>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w3", k_femul29<3>, blocks, d_st, h_st, d_sink);
+    run("f29_mul_split", k_femul29_split<3>, blocks, d_st, h_st, d_sink);
+    run("unif2 narrow", k_femul29_uniform<0>, blocks, d_st, h_st, d_sink);
+    run("unif2 w2", k_femul29_uniform<2>, blocks, d_st, h_st, d_sink);
+    run("unif2 w3", k_femul29_uniform<3>, blocks, d_st, h_st, d_sink);
+    run("butterfly29 n", k_butterfly29<0>, blocks, d_st, h_st, d_sink);
+    run("butterfly29 w3", k_butterfly29<3>, blocks, d_st, h_st, d_sink);
     {
         const size_t n = 65536, words = 17 * n;
         uint32_t* d_out;

@@ -164,6 +164,18 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     constexpr bool ONE = KIND == KIND_FOLD || KIND == KIND_SINGLE;
     constexpr bool SPECIAL = MULTI || ONE;
     constexpr bool FOLD = KIND == KIND_FOLD;
+    // The multiplier's wide-limb form (field29.cuh) is a tenth shorter, but in the high columns it holds about five more
+    // registers. Where four elements and prefetched table entries are alive (the twiddle multiplications of a round, the
+    // inter-pass table) the kinds that already fill the 128 registers of four wavefronts per SIMD (passes that prefetch an inter-pass table,
+    // the folded inverse) would spill with it (the compiler's resource report) and use it in the low columns only,
+    // where it costs none. The multiplication by the 4th root of unity comes when the twiddles are dead and has the
+    // registers in every kind.
+#ifdef STARKHIP_MULW
+    constexpr int MULW_TW = STARKHIP_MULW & 3, MULW = MULW_TW, MULW_U = STARKHIP_MULW >> 2;
+#else
+    constexpr int MULW_TW = (KIND == KIND_FIRST || KIND == KIND_FOLD || KIND == KIND_MID || (KIND == KIND_GENERAL && LOGT == 10)) ? 2 : 3;
+    constexpr int MULW = MULW_TW, MULW_U = 3;
+#endif
     const bool in_raw = (KIND == KIND_FIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
     const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.out_raw != 0;
     const bool load_cfast = (KIND == KIND_LAST3 || ONE) ? false : MULTI ? true : a.load_cfast != 0;
@@ -335,11 +347,11 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             // back to 29-bit limbs by a carry pass. Each later twiddle is requested one multiplication
             // ahead of its use.
             F29 tw2 = f29_load_raw(Wt + 12 * (size_t)(2 * e));
-            x1 = f29_mul(x1, tw1);
+            x1 = f29_mul<MULW_TW>(x1, tw1);
             F29 tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
-            x2 = f29_mul(x2, tw2);
-            x3 = f29_mul(x3, tw3);
-            if (folded) x0 = f29_mul(x0, f29_load_raw(Wt));  // entry 0 of the scaled table is the factor itself
+            x2 = f29_mul<MULW_TW>(x2, tw2);
+            x3 = f29_mul<MULW_TW>(x3, tw3);
+            if (folded) x0 = f29_mul<MULW_TW>(x0, f29_load_raw(Wt));  // entry 0 of the scaled table is the factor itself
             else x0 = f29_carry(x0);
         }
         // radix-4 butterfly, I = w_T^(T/4); every subtrahend is tight or a sum of two tight values
@@ -366,25 +378,25 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                 t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
                 if (!TW_ONE_AHEAD) t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
             }
-            F29 a3 = f29_mul_uniform2(f29_sub(x1, x3), a.iq, a.iq2);
+            F29 a3 = f29_mul_uniform2<MULW_U>(f29_sub(x1, x3), a.iq, a.iq2);
             y1 = f29_add(a1, a3);
             y3 = f29_sub(a1, a3);
             if (tw_on) {
                 if (TW_ONE_AHEAD) {
                     t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
-                    y0 = f29_mul(y0, f29_from_fe(t0));
+                    y0 = f29_mul<MULW>(y0, f29_from_fe(t0));
                     const Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
-                    y1 = f29_mul(y1, f29_from_fe(t1));
+                    y1 = f29_mul<MULW>(y1, f29_from_fe(t1));
                     const Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
-                    y2 = f29_mul(y2, f29_from_fe(t2));
-                    y3 = f29_mul(y3, f29_from_fe(t3));
+                    y2 = f29_mul<MULW>(y2, f29_from_fe(t2));
+                    y3 = f29_mul<MULW>(y3, f29_from_fe(t3));
                 } else {
                     const Fe t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
-                    y0 = f29_mul(y0, f29_from_fe(t0));
+                    y0 = f29_mul<MULW>(y0, f29_from_fe(t0));
                     const Fe t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
-                    y1 = f29_mul(y1, f29_from_fe(t1));
-                    y2 = f29_mul(y2, f29_from_fe(t2));
-                    y3 = f29_mul(y3, f29_from_fe(t3));
+                    y1 = f29_mul<MULW>(y1, f29_from_fe(t1));
+                    y2 = f29_mul<MULW>(y2, f29_from_fe(t2));
+                    y3 = f29_mul<MULW>(y3, f29_from_fe(t3));
                 }
             }
         }
@@ -400,10 +412,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
 #pragma unroll
                 for (int l = 0; l < 8; l++) s.l[l] = a.scale[l];
                 const F29 sc = f29_from_fe(s);
-                y0 = f29_mul(y0, sc);
-                y1 = f29_mul(y1, sc);
-                y2 = f29_mul(y2, sc);
-                y3 = f29_mul(y3, sc);
+                y0 = f29_mul<MULW>(y0, sc);
+                y1 = f29_mul<MULW>(y1, sc);
+                y2 = f29_mul<MULW>(y2, sc);
+                y3 = f29_mul<MULW>(y3, sc);
             }
             uint32_t* dst = a.out + out_w * ((uint64_t)pidx * a.outP + hi * a.outA + lo * a.outB + c * a.outC);
             // offset of output k (in dwords): k * outS, or split at bit ksh of k
