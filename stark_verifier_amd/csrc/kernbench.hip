@@ -437,63 +437,88 @@ __global__ void __launch_bounds__(256) k_blake2s(Stamp* st, uint32_t* sink, uint
     if (acc == 0x1234567) sink[0] = acc;
 }
 
-// The compression with the rotation by 16 folded into its xor as two sub-dword xors (SDWA: each writes one half of the
-// destination from the opposite halves of the sources) instead of v_xor + v_alignbit: 2 + 2 cycles against 2 + 4 if the
-// sub-dword forms issue at the full rate.
+// Instruction-level forms of the compression, timed against the library's (form 0) and checked against it:
+//   bit 0: the rotation by 16 folded into its xor as two sub-dword xors (SDWA: each writes one half of the destination
+//          from the opposite halves of the sources) instead of v_xor + v_alignbit
+//   bit 1: the rotations by 16 and by 8 as byte permutations (v_perm_b32 with a constant selector) instead of v_alignbit
+//   bit 2: a + b + m as two v_add_u32 instead of one v_add3_u32
+template <int F>
 __device__ __forceinline__ uint32_t xor_ror16(uint32_t d, uint32_t a) {
-    uint32_t t;
-    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(t) : "v"(d), "v"(a));
-    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(d), "v"(a));
-    return t;
+    if constexpr ((F & 1) != 0) {
+        uint32_t t;
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(t) : "v"(d), "v"(a));
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(d), "v"(a));
+        return t;
+    } else if constexpr ((F & 2) != 0) {
+        const uint32_t x = d ^ a;
+        return __builtin_amdgcn_perm(x, x, 0x01000302u);
+    } else {
+        return rotr32(d ^ a, 16);
+    }
 }
-#define B2S_G_SDWA(a, b, c, d, x, y) \
-    do {                             \
-        a = a + b + (x);             \
-        d = xor_ror16(d, a);         \
-        c = c + d;                   \
-        b = rotr32(b ^ c, 12);       \
-        a = a + b + (y);             \
-        d = rotr32(d ^ a, 8);        \
-        c = c + d;                   \
-        b = rotr32(b ^ c, 7);        \
-    } while (0)
-#define B2S_ROUND_SDWA(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
-    do {                                                                                       \
-        B2S_G_SDWA(v0, v4, v8, v12, m[s0], m[s1]);                                             \
-        B2S_G_SDWA(v1, v5, v9, v13, m[s2], m[s3]);                                             \
-        B2S_G_SDWA(v2, v6, v10, v14, m[s4], m[s5]);                                            \
-        B2S_G_SDWA(v3, v7, v11, v15, m[s6], m[s7]);                                            \
-        B2S_G_SDWA(v0, v5, v10, v15, m[s8], m[s9]);                                            \
-        B2S_G_SDWA(v1, v6, v11, v12, m[s10], m[s11]);                                          \
-        B2S_G_SDWA(v2, v7, v8, v13, m[s12], m[s13]);                                           \
-        B2S_G_SDWA(v3, v4, v9, v14, m[s14], m[s15]);                                           \
-    } while (0)
-__device__ __forceinline__ void b2s_hash64_sdwa(uint32_t h[8], const uint32_t m[16]) {
+template <int F>
+__device__ __forceinline__ uint32_t xor_ror8(uint32_t d, uint32_t a) {
+    const uint32_t x = d ^ a;
+    if constexpr ((F & 2) != 0) return __builtin_amdgcn_perm(x, x, 0x00030201u);
+    else return rotr32(x, 8);
+}
+template <int F>
+__device__ __forceinline__ uint32_t add_3(uint32_t a, uint32_t b, uint32_t m) {
+    if constexpr ((F & 4) != 0) {
+        uint32_t t, r;
+        asm("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+        asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(m));
+        return r;
+    } else {
+        return a + b + m;
+    }
+}
+template <int F>
+__device__ __forceinline__ void g_form(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t x, uint32_t y) {
+    a = add_3<F>(a, b, x);
+    d = xor_ror16<F>(d, a);
+    c = c + d;
+    b = rotr32(b ^ c, 12);
+    a = add_3<F>(a, b, y);
+    d = xor_ror8<F>(d, a);
+    c = c + d;
+    b = rotr32(b ^ c, 7);
+}
+template <int F>
+__device__ __forceinline__ void b2s_hash64_form(uint32_t h[8], const uint32_t m[16]) {
+    static const uint8_t SIGMA[10][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
     b2s_init(h);
-    uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
-    uint32_t v8 = B2S_IV0, v9 = B2S_IV1, v10 = B2S_IV2, v11 = B2S_IV3;
-    uint32_t v12 = B2S_IV4 ^ 64u, v13 = B2S_IV5, v14 = ~B2S_IV6, v15 = B2S_IV7;
-    B2S_ROUND_SDWA(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    B2S_ROUND_SDWA(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3);
-    B2S_ROUND_SDWA(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4);
-    B2S_ROUND_SDWA(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8);
-    B2S_ROUND_SDWA(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13);
-    B2S_ROUND_SDWA(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9);
-    B2S_ROUND_SDWA(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11);
-    B2S_ROUND_SDWA(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10);
-    B2S_ROUND_SDWA(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5);
-    B2S_ROUND_SDWA(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0);
-    h[0] ^= v0 ^ v8; h[1] ^= v1 ^ v9; h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
-    h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+    uint32_t v[16] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], B2S_IV0, B2S_IV1, B2S_IV2, B2S_IV3,
+                      B2S_IV4 ^ 64u, B2S_IV5, ~B2S_IV6, B2S_IV7};
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint8_t* s = SIGMA[r];
+        g_form<F>(v[0], v[4], v[8], v[12], m[s[0]], m[s[1]]);
+        g_form<F>(v[1], v[5], v[9], v[13], m[s[2]], m[s[3]]);
+        g_form<F>(v[2], v[6], v[10], v[14], m[s[4]], m[s[5]]);
+        g_form<F>(v[3], v[7], v[11], v[15], m[s[6]], m[s[7]]);
+        g_form<F>(v[0], v[5], v[10], v[15], m[s[8]], m[s[9]]);
+        g_form<F>(v[1], v[6], v[11], v[12], m[s[10]], m[s[11]]);
+        g_form<F>(v[2], v[7], v[8], v[13], m[s[12]], m[s[13]]);
+        g_form<F>(v[3], v[4], v[9], v[14], m[s[14]], m[s[15]]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
 }
-__global__ void __launch_bounds__(256) k_blake2s_sdwa(Stamp* st, uint32_t* sink, uint32_t s) {
+template <int F>
+__global__ void __launch_bounds__(256) k_blake2s_form(Stamp* st, uint32_t* sink, uint32_t s) {
     uint32_t h[8], m[16];
     for (int i = 0; i < 16; i++) m[i] = s * (i + 7) + threadIdx.x * 2654435761u;
     unsigned long long c0, r0;
     stamp_begin(c0, r0);
 #pragma unroll 1
     for (int it = 0; it < ITERS; it++) {
-        b2s_hash64_sdwa(h, m);
+        b2s_hash64_form<F>(h, m);
         for (int i = 0; i < 8; i++) m[i] = h[i];
     }
     stamp_end(st, c0, r0);
@@ -501,17 +526,23 @@ __global__ void __launch_bounds__(256) k_blake2s_sdwa(Stamp* st, uint32_t* sink,
     for (int i = 0; i < 8; i++) acc ^= h[i];
     if (acc == 0x1234567) sink[0] = acc;
 }
-// both forms on the same messages: out[0..7] plain, out[8..15] sub-dword form
+// every form on the same messages: out[8 f .. 8 f + 7] = digest of form f (0 = the library's)
 __global__ void k_blake2s_forms(uint32_t* out, uint32_t s) {
-    uint32_t h[8], g[8], m[16];
+    uint32_t h[8], m[16];
     for (int i = 0; i < 16; i++) m[i] = s * (i + 7) + (threadIdx.x + blockIdx.x * blockDim.x) * 2654435761u;
+    uint32_t* o = out + 64 * (size_t)(threadIdx.x + blockIdx.x * blockDim.x);
     b2s_hash64(h, m);
-    b2s_hash64_sdwa(g, m);
-    uint32_t* o = out + 16 * (size_t)(threadIdx.x + blockIdx.x * blockDim.x);
-    for (int i = 0; i < 8; i++) {
-        o[i] = h[i];
-        o[8 + i] = g[i];
-    }
+    for (int i = 0; i < 8; i++) o[i] = h[i];
+    b2s_hash64_form<1>(h, m);
+    for (int i = 0; i < 8; i++) o[8 + i] = h[i];
+    b2s_hash64_form<2>(h, m);
+    for (int i = 0; i < 8; i++) o[16 + i] = h[i];
+    b2s_hash64_form<4>(h, m);
+    for (int i = 0; i < 8; i++) o[24 + i] = h[i];
+    b2s_hash64_form<6>(h, m);
+    for (int i = 0; i < 8; i++) o[32 + i] = h[i];
+    b2s_hash64_form<0>(h, m);
+    for (int i = 0; i < 8; i++) o[40 + i] = h[i];
 }
 
 typedef void (*kern_t)(Stamp*, uint32_t*, uint32_t);
@@ -607,17 +638,21 @@ int main(int argc, char** argv) {
     run("prod_karatsuba", k_prod_kara, blocks, d_st, h_st, d_sink);
     run("prod_fp64", k_prod_fp64, blocks, d_st, h_st, d_sink);
     run("blake2s", k_blake2s, blocks, d_st, h_st, d_sink);
-    run("blake2s sdwa", k_blake2s_sdwa, blocks, d_st, h_st, d_sink);
+    run("blake2s sdwa16", k_blake2s_form<1>, blocks, d_st, h_st, d_sink);
+    run("blake2s perm", k_blake2s_form<2>, blocks, d_st, h_st, d_sink);
+    run("blake2s 2adds", k_blake2s_form<4>, blocks, d_st, h_st, d_sink);
+    run("blake2s perm+2a", k_blake2s_form<6>, blocks, d_st, h_st, d_sink);
     {
         const size_t n = 16384;
         uint32_t* d_out;
-        std::vector<uint32_t> h(16 * n);
-        CHECK(hipMalloc(&d_out, 64 * n));
+        std::vector<uint32_t> h(64 * n);
+        CHECK(hipMalloc(&d_out, 256 * n));
         hipLaunchKernelGGL(k_blake2s_forms, dim3(n / 256), dim3(256), 0, 0, d_out, 777u);
-        CHECK(hipMemcpy(h.data(), d_out, 64 * n, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h.data(), d_out, 256 * n, hipMemcpyDeviceToHost));
         size_t bad = 0;
         for (size_t t = 0; t < n; t++)
-            for (int i = 0; i < 8; i++) bad += h[16 * t + i] != h[16 * t + 8 + i];
+            for (int f = 1; f < 6; f++)
+                for (int i = 0; i < 8; i++) bad += h[64 * t + i] != h[64 * t + 8 * f + i];
         printf("blake2s forms agree on %zu messages: %s\n", n, bad ? "NO" : "yes");
         CHECK(hipFree(d_out));
     }
