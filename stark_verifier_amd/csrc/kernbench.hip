@@ -587,11 +587,21 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&d_st, sizeof(Stamp) * blocks * 4));
     CHECK(hipMalloc(&d_sink, 64));
     printf("waves/SIMD requested %d (256-thread blocks, %d blocks)\n", wps, blocks);
+    // the clock takes a second or so of load to settle (the first kernels of a cold run report 2.0 GHz, later ones 2.3-2.4):
+    // run the multiplier untimed for that long first, so that the rates below are comparable with each other
+    for (int r = 0; r < 400; r++) hipLaunchKernelGGL(k_femul29<0>, dim3(blocks), dim3(256), 0, 0, d_st, d_sink, 1u);
+    CHECK(hipDeviceSynchronize());
     run("fe_mul", k_femul, blocks, d_st, h_st, d_sink);
     run("butterfly", k_butterfly, blocks, d_st, h_st, d_sink);
+    // (twice, the second time in the opposite order, as a check that the order does not matter)
     run("f29_mul narrow", k_femul29<0>, blocks, d_st, h_st, d_sink);
     run("f29_mul w2", k_femul29<2>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w1", k_femul29<1>, blocks, d_st, h_st, d_sink);
     run("f29_mul w3", k_femul29<3>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w3", k_femul29<3>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w1", k_femul29<1>, blocks, d_st, h_st, d_sink);
+    run("f29_mul w2", k_femul29<2>, blocks, d_st, h_st, d_sink);
+    run("f29_mul narrow", k_femul29<0>, blocks, d_st, h_st, d_sink);
     run("f29_mul_split", k_femul29_split<3>, blocks, d_st, h_st, d_sink);
     run("unif2 narrow", k_femul29_uniform<0>, blocks, d_st, h_st, d_sink);
     run("unif2 w2", k_femul29_uniform<2>, blocks, d_st, h_st, d_sink);
