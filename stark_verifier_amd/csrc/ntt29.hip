@@ -453,6 +453,9 @@ extern "C" int stark_debug_read_stamps(unsigned long long* out) {
 template <int LOGT, int KIND>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
     size_t lds = ntt29_pass_lds_bytes(LOGT, (int)a.log_c);
+    // STARKHIP_LDS_PAD=bytes: unused LDS on top, to measure how the kernel responds to fewer resident workgroups
+    static const size_t lds_pad = getenv("STARKHIP_LDS_PAD") ? (size_t)atol(getenv("STARKHIP_LDS_PAD")) : 0;
+    lds += lds_pad;
     unsigned threads = (1u << (LOGT - 2)) << a.log_c;
     if (threads > 1024 || lds > 160 * 1024) return hipErrorInvalidConfiguration;
     // per device: dynamic LDS above 64 KiB must be opted into. Contexts of several host threads may get here at once:
