@@ -996,11 +996,7 @@ extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs,
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t o_who = up(8 * mc), o_io = o_who + up(4 * mc);
         uint8_t* d = nullptr;
-        if (hipMalloc((void**)&d, o_io + up(64 * mc)) != hipSuccess) return STARK_ERR_NOMEM;
-        struct Free {
-            uint8_t* p;
-            ~Free() { (void)hipFree(p); }
-        } guard{d};
+        if ((rc = fast_resident_scratch(ctx, o_io + up(64 * mc), &d)) != STARK_OK) return rc;
         uint32_t inv[8];
         hostfe::to_limbs(S.P.inv_last_m1, inv);
         if (hipMemcpyAsync(d, bases.data() + k0, 8 * mc, hipMemcpyHostToDevice, st) != hipSuccess ||

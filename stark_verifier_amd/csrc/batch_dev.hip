@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <thread>
@@ -164,15 +165,26 @@ struct DevTemplate : CtxAttachment {
     TWord* words = nullptr;
     uint32_t n_words = 0;
     // grow-only device buffers kept across calls: [0] descriptors, lanes and partial verdicts; [1] an uploaded chunk
-    // with its per-proof offsets, inputs and verdicts; [2] verdicts of resident proofs
-    uint8_t* buf[3] = {nullptr, nullptr, nullptr};
-    size_t buf_bytes[3] = {0, 0, 0};
+    // with its per-proof offsets, inputs and verdicts; [2] verdicts of resident proofs; [3] offsets, positions and inputs
+    // of resident proofs
+    uint8_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t buf_bytes[4] = {0, 0, 0, 0};
     // pipelined host path: kernels of piece k run on `compute` while piece k + 1 is on the link (the context's stream);
     // `pinned` carries the per-proof offsets and inputs up and the verdicts down without a blocking pageable copy
     hipStream_t compute = nullptr;
     uint8_t* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // the scalar checks of a call run on `side` beside its branch launch (fork after the samples, join before the
+    // verdicts): they are short, latency-bound launches that fill the gaps of the long one
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~DevTemplate() override {
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (compute) {
             (void)hipStreamSynchronize(compute);
             (void)hipStreamDestroy(compute);
@@ -484,26 +496,62 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     hipLaunchKernelGGL(vdesc_kernel, dim3((N_BRANCH + 255) / 256, m), dim3(256), 0, st, D->branches, d_base, m, samples,
                        (uint64_t*)(d + o_rec), (uint64_t*)(d + o_root), (uint32_t*)(d + o_idx));
     F_TRY(hipGetLastError());
+    // fork: the checks need the samples (and the caller's inputs, which are ordered before this point on st)
+    const bool overlap = !(getenv("STARKHIP_BATCH_OVERLAP") && atoi(getenv("STARKHIP_BATCH_OVERLAP")) == 0);
+    hipStream_t sc = st;
+    if (overlap) {
+        if (!D->side) F_TRY(hipStreamCreateWithFlags(&D->side, hipStreamNonBlocking));
+        if (!D->ev_fork) F_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
+        if (!D->ev_join) F_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
+        F_TRY(hipEventRecord(D->ev_fork, st));
+        F_TRY(hipStreamWaitEvent(D->side, D->ev_fork, 0));
+        sc = D->side;
+    }
     Buckets B = {};
     B.n = (uint32_t)T.buckets.size();
     if (B.n > 8) return STARK_ERR_UNSUPPORTED;
+    // all buckets of branches in one launch, deepest first (a launch per bucket would pay a tail each: the last
+    // wavefronts of a launch run their chain of compressions on an emptying chip); STARKHIP_BATCH_GATHER=split keeps
+    // the launch per bucket
+    const bool one_launch = !(getenv("STARKHIP_BATCH_GATHER") && !strcmp(getenv("STARKHIP_BATCH_GATHER"), "split"));
+    uint32_t order[8];
+    for (uint32_t b = 0; b < B.n; b++) order[b] = b;
+    std::stable_sort(order, order + B.n, [&](uint32_t x, uint32_t y) { return T.buckets[x].w > T.buckets[y].w; });
+    GatherGroups G = {};
+    G.n = B.n;
     for (uint32_t b = 0; b < B.n; b++) {
         const TBucket& k = T.buckets[b];
         B.base[b] = k.base;
         B.count[b] = k.count;
         const size_t first = (size_t)k.base * m, n = (size_t)k.count * m;
-        F_TRY(launch_merkle_gather(d_blob, (const uint64_t*)(d + o_rec) + first, k.vs, k.w, (const uint32_t*)(d + o_idx) + first,
-                                   (const uint64_t*)(d + o_root) + first, n, d + o_acc + first, st));
+        if ((first + n) >> 32) return STARK_ERR_UNSUPPORTED;
+        if (!one_launch)
+            F_TRY(launch_merkle_gather(d_blob, (const uint64_t*)(d + o_rec) + first, k.vs, k.w, (const uint32_t*)(d + o_idx) + first,
+                                       (const uint64_t*)(d + o_root) + first, n, d + o_acc + first, st));
     }
-    hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, st, D->fri, d_blob, d_base, m, samples,
+    for (uint32_t g = 0; g < B.n; g++) {
+        const TBucket& k = T.buckets[order[g]];
+        G.first[g] = (uint32_t)((size_t)k.base * m);
+        G.count[g] = (uint32_t)((size_t)k.count * m);
+        G.value_size[g] = k.vs;
+        G.num_witnesses[g] = k.w;
+    }
+    if (one_launch)
+        F_TRY(launch_merkle_gather_groups(d_blob, (const uint64_t*)(d + o_rec), (const uint32_t*)(d + o_idx),
+                                          (const uint64_t*)(d + o_root), d + o_acc, G, st));
+    hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, sc, D->fri, d_blob, d_base, m, samples,
                        (FriLane*)(d + o_fri));
-    hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, st, D->con, d_blob, d_base, m, samples,
+    hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, sc, D->con, d_blob, d_base, m, samples,
                        (ConstraintLane*)(d + o_con));
-    hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, st, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
+    hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, sc, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
     F_TRY(hipGetLastError());
-    F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, st));
+    F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, sc));
     F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
-                                  d + o_chk + (size_t)N_FRI * m, st));
+                                  d + o_chk + (size_t)N_FRI * m, sc));
+    if (sc != st) {
+        F_TRY(hipEventRecord(D->ev_join, sc));
+        F_TRY(hipStreamWaitEvent(st, D->ev_join, 0));
+    }
     hipLaunchKernelGGL(vstatus_kernel, dim3(m), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
     F_TRY(hipGetLastError());
     return STARK_OK;
@@ -664,6 +712,15 @@ int fast_verify(stark_ctx* ctx, const uint8_t* chunk, size_t chunk_len, const ui
     return fast_verify_resident(ctx, d, (const uint64_t*)(d + o_base), (const uint32_t*)(d + o_io), mc, CP, d_mini, status_out);
 }
 
+// Kept buffer 3, at least `bytes` long: the per-call device scratch of the resident entry point (no allocation and no
+// release, which waits for the device, once it has grown to the largest call).
+int fast_resident_scratch(stark_ctx* ctx, size_t bytes, uint8_t** out) {
+    DevTemplate* D;
+    int rc = get_dev_template(ctx, &D);
+    if (rc != STARK_OK) return rc;
+    return kept_buffer(ctx, D, 3, bytes, out);
+}
+
 // Device-resident proofs at d_proofs + i * stride: canonical_out[i] (host) = 1 where the structure words match.
 int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t n, uint8_t* canonical_out) {
     if (n == 0) return STARK_OK;
@@ -675,12 +732,8 @@ int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t str
     DevTemplate* D;
     int rc = get_dev_template(ctx, &D);
     if (rc != STARK_OK) return rc;
-    uint8_t* d = nullptr;
-    F_TRY(hipMalloc((void**)&d, n));
-    struct Free {
-        uint8_t* p;
-        ~Free() { (void)hipFree(p); }
-    } guard{d};
+    uint8_t* d = nullptr;  // kept buffer 2 (the verdicts of the checks that follow reuse it: this call ends synchronised)
+    if ((rc = kept_buffer(ctx, D, 2, (n + 255) & ~(size_t)255, &d)) != STARK_OK) return rc;
     hipLaunchKernelGGL(vclassify_kernel, dim3((unsigned)n), dim3(256), 0, st, d_proofs, stride, D->words, D->n_words, d);
     F_TRY(hipGetLastError());
     F_TRY(hipMemcpyAsync(canonical_out, d, n, hipMemcpyDeviceToHost, st));

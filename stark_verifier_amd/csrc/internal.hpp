@@ -104,6 +104,16 @@ hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, ui
                                 const uint32_t* indices, const uint64_t* root_off, size_t n, uint8_t* accept,
                                 hipStream_t stream);
 
+// The same for up to eight groups of lanes in one launch: group g covers lanes first[g] .. first[g] + count[g] of the
+// arrays and has its own value size and witness count; groups run in the order given (start[] is filled in here).
+struct GatherGroups {
+    static constexpr uint32_t MAX = 8;
+    uint32_t n;
+    uint32_t first[MAX], count[MAX], value_size[MAX], num_witnesses[MAX], start[MAX];
+};
+hipError_t launch_merkle_gather_groups(const uint8_t* blob, const uint64_t* rec_off, const uint32_t* indices,
+                                       const uint64_t* root_off, uint8_t* accept, GatherGroups G, hipStream_t stream);
+
 hipError_t launch_merkle_build(uint8_t* nodes, unsigned log_leaves, hipStream_t stream);
 hipError_t launch_sample_indices(const uint8_t* seeds, size_t n, uint32_t count, uint32_t real_modulus, uint32_t exclude,
                                  uint32_t* out, hipStream_t stream);
@@ -164,6 +174,7 @@ int fast_session_piece(stark_ctx* ctx, FastSession* s, const uint64_t* bases, co
                        const CheckParams& CP, const uint32_t* d_mini);
 int fast_session_end(stark_ctx* ctx, FastSession* s, uint8_t* status_out);
 // structure check of device-resident proofs at d_proofs + i * stride; canonical_out is a host array
+int fast_resident_scratch(stark_ctx* ctx, size_t bytes, uint8_t** out);
 int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t n, uint8_t* canonical_out);
 // d_io[k] = (canonical input, slope) of proof d_who[k] from device-resident n x 8-limb inputs / outputs
 int fast_make_io(stark_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_outputs, const uint32_t* d_who, size_t mc,

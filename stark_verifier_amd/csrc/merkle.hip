@@ -168,13 +168,12 @@ __device__ __forceinline__ uint4 load16_a4(const uint8_t* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// One branch: lane i of the launch's arrays (record, index, root, verdict).
 template <bool VS32>
-__global__ void __launch_bounds__(256)
-merkle_gather_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off, uint32_t value_size,
-                     uint32_t num_witnesses, const uint32_t* __restrict__ indices,
-                     const uint64_t* __restrict__ root_off, size_t n, uint8_t* __restrict__ accept) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void gather_branch(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off,
+                                              uint32_t value_size, uint32_t num_witnesses,
+                                              const uint32_t* __restrict__ indices, const uint64_t* __restrict__ root_off,
+                                              size_t i, uint8_t* __restrict__ accept) {
     uint32_t a = indices[i];
     uint32_t ld4_log = num_witnesses - 1;
     uint32_t idx = (a >> ld4_log) + 4u * (a & ((1u << ld4_log) - 1u));
@@ -237,6 +236,43 @@ merkle_gather_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restric
     accept[i] = diff == 0 ? 1 : 0;
 }
 
+template <bool VS32>
+__global__ void __launch_bounds__(256)
+merkle_gather_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off, uint32_t value_size,
+                     uint32_t num_witnesses, const uint32_t* __restrict__ indices,
+                     const uint64_t* __restrict__ root_off, size_t n, uint8_t* __restrict__ accept) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gather_branch<VS32>(blob, rec_off, value_size, num_witnesses, indices, root_off, i, accept);
+}
+
+// Several groups of branches, each with its own (value_size, num_witnesses), in one launch: a launch per group pays
+// that group's tail (its last wavefronts run their dependent compressions on an emptying chip) once per group; here the
+// groups follow each other in the order given (deepest first leaves only the shallowest group's tail). Every group
+// starts on a wavefront boundary of the launch's lane numbering, so a wavefront never mixes depths.
+__global__ void __launch_bounds__(256)
+merkle_gather_groups_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off,
+                            const uint32_t* __restrict__ indices, const uint64_t* __restrict__ root_off,
+                            uint8_t* __restrict__ accept, const GatherGroups G) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    // the group this lane falls into (compile-time indices into the argument block: selects, no indexed loads)
+    uint32_t start = G.start[0], count = G.count[0], first = G.first[0], vs = G.value_size[0], w = G.num_witnesses[0];
+#pragma unroll
+    for (uint32_t k = 1; k < GatherGroups::MAX; k++)
+        if (k < G.n && v >= G.start[k]) {
+            start = G.start[k];
+            count = G.count[k];
+            first = G.first[k];
+            vs = G.value_size[k];
+            w = G.num_witnesses[k];
+        }
+    const uint32_t off = v - start;
+    if (off >= count) return;
+    const size_t i = (size_t)first + off;
+    if (vs == 32) gather_branch<true>(blob, rec_off, 32u, w, indices, root_off, i, accept);
+    else gather_branch<false>(blob, rec_off, vs, w, indices, root_off, i, accept);
+}
+
 // value_size must be a multiple of 4 and every offset a multiple of 4 (checked by the caller)
 hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, uint32_t value_size, uint32_t num_witnesses,
                                 const uint32_t* indices, const uint64_t* root_off, size_t n, uint8_t* accept,
@@ -249,6 +285,23 @@ hipError_t launch_merkle_gather(const uint8_t* blob, const uint64_t* rec_off, ui
     else
         hipLaunchKernelGGL(merkle_gather_kernel<false>, grid, block, 0, stream, blob, rec_off, value_size, num_witnesses,
                            indices, root_off, n, accept);
+    return hipGetLastError();
+}
+
+hipError_t launch_merkle_gather_groups(const uint8_t* blob, const uint64_t* rec_off, const uint32_t* indices,
+                                       const uint64_t* root_off, uint8_t* accept, GatherGroups G, hipStream_t stream) {
+    if (G.n == 0 || G.n > GatherGroups::MAX) return G.n == 0 ? hipSuccess : hipErrorInvalidValue;
+    uint64_t at = 0;
+    for (uint32_t g = 0; g < G.n; g++) {
+        if (G.value_size[g] < 32 || (G.value_size[g] & 3u) || G.num_witnesses[g] == 0 || G.num_witnesses[g] > 31)
+            return hipErrorInvalidValue;
+        G.start[g] = (uint32_t)at;
+        at += ((uint64_t)G.count[g] + 63) & ~(uint64_t)63;
+        if (at >= (1ull << 32)) return hipErrorInvalidValue;
+    }
+    if (at == 0) return hipSuccess;
+    hipLaunchKernelGGL(merkle_gather_groups_kernel, dim3((unsigned)((at + 255) / 256)), dim3(256), 0, stream, blob, rec_off,
+                       indices, root_off, accept, G);
     return hipGetLastError();
 }
 

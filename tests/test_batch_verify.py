@@ -134,6 +134,17 @@ def test_pipelined_upload_pieces_give_the_same_answer(proof_bytes, monkeypatch, 
     monkeypatch.setenv("STARKHIP_HOST_THREADS", "1")
     a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
     assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
+    # the launch structure of a piece: a branch launch per bucket instead of one for all buckets, and the scalar checks
+    # behind the branch launch instead of beside it on a second stream
+    monkeypatch.setenv("STARKHIP_BATCH_GATHER", "split")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
+    monkeypatch.setenv("STARKHIP_BATCH_OVERLAP", "0")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
+    monkeypatch.delenv("STARKHIP_BATCH_GATHER")
+    a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    assert np.array_equal(a, ref_a) and np.array_equal(s, ref_s)
 
 
 def _merkle_blind_hooks():
