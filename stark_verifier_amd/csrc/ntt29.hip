@@ -166,14 +166,15 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     constexpr bool FOLD = KIND == KIND_FOLD;
     // The multiplier's wide-limb form (field29.cuh) is a tenth shorter, but in the high columns it holds about five more
     // registers. Where four elements and prefetched table entries are alive (the twiddle multiplications of a round, the
-    // inter-pass table) the kinds that already fill the 128 registers of four wavefronts per SIMD (passes that prefetch an inter-pass table,
-    // the folded inverse) would spill with it (the compiler's resource report) and use it in the low columns only,
-    // where it costs none. The multiplication by the 4th root of unity comes when the twiddles are dead and has the
-    // registers in every kind.
+    // inter-pass table) the kinds that already fill the 128 registers of four wavefronts per SIMD (passes that
+    // prefetch an inter-pass table, the folded inverse) would spill with it (the compiler's resource report) and use
+    // it in the low columns only, where it costs none; at 1024-point tiles the first and middle passes do have the
+    // registers (with the scheduling option this file is built with, see the Makefile). The multiplication by the 4th
+    // root of unity comes when the twiddles are dead and has the registers in every kind.
 #ifdef STARKHIP_MULW
     constexpr int MULW_TW = STARKHIP_MULW & 3, MULW = MULW_TW, MULW_U = STARKHIP_MULW >> 2;
 #else
-    constexpr int MULW_TW = (KIND == KIND_FIRST || KIND == KIND_FOLD || KIND == KIND_MID || (KIND == KIND_GENERAL && LOGT == 10)) ? 2 : 3;
+    constexpr int MULW_TW = (((KIND == KIND_FIRST || KIND == KIND_MID) && LOGT != 10) || KIND == KIND_FOLD || (KIND == KIND_GENERAL && LOGT == 10)) ? 2 : 3;
     constexpr int MULW = MULW_TW, MULW_U = 3;
 #endif
     const bool in_raw = (KIND == KIND_FIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
