@@ -493,13 +493,14 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     SeedOffs so;
     memcpy(so.off, T.seed_off, sizeof so.off);
     hipLaunchKernelGGL(vsample_kernel, dim3((m * (NL + 1) + 63) / 64), dim3(64), 0, st, d_blob, d_base, m, so, samples);
-    hipLaunchKernelGGL(vdesc_kernel, dim3((N_BRANCH + 255) / 256, m), dim3(256), 0, st, D->branches, d_base, m, samples,
-                       (uint64_t*)(d + o_rec), (uint64_t*)(d + o_root), (uint32_t*)(d + o_idx));
     F_TRY(hipGetLastError());
-    // fork: the checks need the samples (and the caller's inputs, which are ordered before this point on st)
+    // fork: the scalar checks need the samples (and the caller's inputs, which are ordered before this point on st).
+    // They go out first: short launches that do not fill the chip, which behind the branch launch would wait for its
+    // workgroups to drain (measured: five times their own duration).
     const bool overlap = !(getenv("STARKHIP_BATCH_OVERLAP") && atoi(getenv("STARKHIP_BATCH_OVERLAP")) == 0);
     hipStream_t sc = st;
     if (overlap) {
+        // (a plain stream: with a high-priority one, calls of 1,250 proofs stopped making progress on this system)
         if (!D->side) F_TRY(hipStreamCreateWithFlags(&D->side, hipStreamNonBlocking));
         if (!D->ev_fork) F_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
         if (!D->ev_join) F_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
@@ -507,6 +508,19 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
         F_TRY(hipStreamWaitEvent(D->side, D->ev_fork, 0));
         sc = D->side;
     }
+    hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, sc, D->fri, d_blob, d_base, m, samples,
+                       (FriLane*)(d + o_fri));
+    hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, sc, D->con, d_blob, d_base, m, samples,
+                       (ConstraintLane*)(d + o_con));
+    hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, sc, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
+    F_TRY(hipGetLastError());
+    F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, sc));
+    F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
+                                  d + o_chk + (size_t)N_FRI * m, sc));
+    if (sc != st) F_TRY(hipEventRecord(D->ev_join, sc));
+    hipLaunchKernelGGL(vdesc_kernel, dim3((N_BRANCH + 255) / 256, m), dim3(256), 0, st, D->branches, d_base, m, samples,
+                       (uint64_t*)(d + o_rec), (uint64_t*)(d + o_root), (uint32_t*)(d + o_idx));
+    F_TRY(hipGetLastError());
     Buckets B = {};
     B.n = (uint32_t)T.buckets.size();
     if (B.n > 8) return STARK_ERR_UNSUPPORTED;
@@ -539,19 +553,7 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     if (one_launch)
         F_TRY(launch_merkle_gather_groups(d_blob, (const uint64_t*)(d + o_rec), (const uint32_t*)(d + o_idx),
                                           (const uint64_t*)(d + o_root), d + o_acc, G, st));
-    hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, sc, D->fri, d_blob, d_base, m, samples,
-                       (FriLane*)(d + o_fri));
-    hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, sc, D->con, d_blob, d_base, m, samples,
-                       (ConstraintLane*)(d + o_con));
-    hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, sc, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
-    F_TRY(hipGetLastError());
-    F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, sc));
-    F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
-                                  d + o_chk + (size_t)N_FRI * m, sc));
-    if (sc != st) {
-        F_TRY(hipEventRecord(D->ev_join, sc));
-        F_TRY(hipStreamWaitEvent(st, D->ev_join, 0));
-    }
+    if (sc != st) F_TRY(hipStreamWaitEvent(st, D->ev_join, 0));
     hipLaunchKernelGGL(vstatus_kernel, dim3(m), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
     F_TRY(hipGetLastError());
     return STARK_OK;
