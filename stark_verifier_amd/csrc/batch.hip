@@ -23,6 +23,7 @@
 #include <map>
 #include <new>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../include/starkhip.h"
@@ -533,10 +534,22 @@ using namespace starkhip::batch;
 struct Setup {
     Params P;
     CheckParams CP;
-    uint32_t* d_mini = nullptr;  // constants_mini_polynomial on the device (when the scalar checks run there)
+    uint32_t* d_mini = nullptr;  // constants_mini_polynomial on the device (owned by the context's SetupCache)
     bool field_on_host = false, skip_merkle = false, force_flatten = false, force_general = false;
-    ~Setup() { (void)hipFree(d_mini); }
 };
+
+// What make_setup derives from (num_steps, round_constants) alone, kept in the context: two 256-bit powers, an inverse
+// and a 64-point inverse transform with its upload and download are a fifth of a millisecond per call, as much as the
+// kernels of 200 proofs. One parameter set is kept at a time; every call ends synchronised, so replacing it is safe.
+struct SetupCache : CtxAttachment {
+    uint64_t num_steps = 0;
+    std::vector<uint32_t> consts;
+    Params P;
+    CheckParams CP;
+    uint32_t* d_mini = nullptr;
+    ~SetupCache() override { (void)hipFree(d_mini); }
+};
+constexpr int SETUP_SLOT = 2;
 
 // early: ST_ACCEPT when proofs have to be looked at, else the status every proof gets (lib.rs:101-111, :120-123)
 static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_constants, size_t n_constants, Setup& S,
@@ -549,6 +562,25 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
     if (num_steps > (1ull << 32) / 8 || !pow2(num_steps) || !pow2(n_constants) || n_constants > num_steps) {
         early = ST_PARAMS;
         return STARK_OK;
+    }
+    // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host (equivalent paths)
+    const char* fenv = getenv("STARKHIP_BATCH_FIELD");
+    S.field_on_host = (fenv && strcmp(fenv, "host") == 0) || (flags & STARK_DIAG_HOST_FIELD_CHECKS);
+    // test only, reachable through stark_mimc_verify_batch_diag alone: the scalar checks decide even when a branch
+    // mismatched, so damaged values exercise every check
+    S.skip_merkle = (flags & STARK_DIAG_IGNORE_MERKLE) != 0;
+    const char* menv = getenv("STARKHIP_BATCH_MERKLE");
+    S.force_flatten = menv && strcmp(menv, "flatten") == 0;
+    const char* penv = getenv("STARKHIP_BATCH_PATH");
+    S.force_general = (penv && strcmp(penv, "general") == 0) || (flags & STARK_DIAG_GENERAL_PATH);
+    if (SetupCache* c = static_cast<SetupCache*>(ctx_get_attachment(ctx, SETUP_SLOT))) {
+        if (c->num_steps == num_steps && c->consts.size() == 8 * n_constants &&
+            memcmp(c->consts.data(), round_constants, 32 * n_constants) == 0) {
+            S.P = c->P;
+            S.CP = c->CP;
+            S.d_mini = c->d_mini;
+            return STARK_OK;
+        }
     }
     P.num_steps = num_steps;
     P.precision = num_steps * 8;
@@ -582,16 +614,6 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
         if (rc != STARK_OK) return rc;
         for (size_t i = 0; i < n_constants; i++) P.mini_poly.push_back(hostfe::from_limbs(out.data() + 8 * i));
     }
-    // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host (equivalent paths)
-    const char* fenv = getenv("STARKHIP_BATCH_FIELD");
-    S.field_on_host = (fenv && strcmp(fenv, "host") == 0) || (flags & STARK_DIAG_HOST_FIELD_CHECKS);
-    // test only, reachable through stark_mimc_verify_batch_diag alone: the scalar checks decide even when a branch
-    // mismatched, so damaged values exercise every check
-    S.skip_merkle = (flags & STARK_DIAG_IGNORE_MERKLE) != 0;
-    const char* menv = getenv("STARKHIP_BATCH_MERKLE");
-    S.force_flatten = menv && strcmp(menv, "flatten") == 0;
-    const char* penv = getenv("STARKHIP_BATCH_PATH");
-    S.force_general = (penv && strcmp(penv, "general") == 0) || (flags & STARK_DIAG_GENERAL_PATH);
     hostfe::to_limbs(P.g2, CP.g2);
     hostfe::to_limbs(hostfe::pow_u64(P.g2, P.precision / 4), CP.q4);
     hostfe::to_limbs(P.last_step, CP.last_step);
@@ -600,12 +622,19 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
     while ((1ull << CP.log_steps) < P.num_steps) CP.log_steps++;
     while ((1ull << CP.log_skips2) < P.skips2) CP.log_skips2++;
     CP.n_coeffs = (uint32_t)P.mini_poly.size();
-    if (!S.field_on_host) {
+    std::unique_ptr<SetupCache> c(new SetupCache);
+    {
         std::vector<uint32_t> mp(8 * P.mini_poly.size());
         for (size_t i = 0; i < P.mini_poly.size(); i++) hostfe::to_limbs(hostfe::canon(P.mini_poly[i]), &mp[8 * i]);
-        if (hipMalloc((void**)&S.d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
-        if (hipMemcpy(S.d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return STARK_ERR_HIP;
+        if (hipMalloc((void**)&c->d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
+        if (hipMemcpy(c->d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return STARK_ERR_HIP;
     }
+    c->num_steps = num_steps;
+    c->consts.assign(round_constants, round_constants + 8 * n_constants);
+    c->P = P;
+    c->CP = CP;
+    S.d_mini = c->d_mini;
+    ctx_set_attachment(ctx, SETUP_SLOT, c.release());
     return STARK_OK;
 }
 

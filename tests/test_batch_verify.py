@@ -85,6 +85,12 @@ def test_batch_public_parameters(proof_bytes):
     a, s = batch.verify_mimc_batch(good, 3, 8192, bad, output)
     assert list(a) == [0, 0] and list(s) == [6, 6]
     assert not _ref_accepts(proof_bytes, 3, 8192, bad, output)
+    # (the context keeps what it derived from the last parameter set: the right constants again, and once more)
+    for _ in range(2):
+        a, s = batch.verify_mimc_batch(good, 3, 8192, consts, output)
+        assert list(a) == [1, 1] and list(s) == [0, 0]
+    a, s = batch.verify_mimc_batch(good, 3, 8192, bad, output)
+    assert list(a) == [0, 0] and list(s) == [6, 6]
     # parameter checks that make the reference return false (src/lib.rs:101-111)
     for steps, cs in ((8191, consts), (8192, consts[:63]), (2**30, consts), (32, consts)):
         a, s = batch.verify_mimc_batch(good, 3, steps, cs, output)
