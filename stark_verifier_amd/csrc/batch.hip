@@ -1006,12 +1006,31 @@ extern "C" int stark_mimc_verify_batch_dev(stark_ctx* ctx, const void* d_proofs,
     hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
     const bool use_fast = !S.force_general && !S.field_on_host && !S.force_flatten;
     std::vector<uint8_t> canon(n_proofs, 0), stv(n_proofs, 0);
-    if (use_fast && (rc = fast_classify_resident(ctx, (const uint8_t*)d_proofs, proof_stride, n_proofs, canon.data())) != STARK_OK)
+    // One pass (default): structure words and checks of every proof are queued together and answered in one copy, the
+    // proofs of another structure are then redone on the general path. STARKHIP_BATCH_RESIDENT=twostep asks for the
+    // structure first and runs the checks on the matching proofs only (one more round trip per call).
+    const char* renv = getenv("STARKHIP_BATCH_RESIDENT");
+    const bool one_pass = use_fast && !(renv && strcmp(renv, "twostep") == 0);
+    if (one_pass) {
+        uint32_t inv[8];
+        hostfe::to_limbs(S.P.inv_last_m1, inv);
+        for (size_t k0 = 0; k0 < n_proofs; k0 += 16384) {
+            const size_t mc = std::min<size_t>(16384, n_proofs - k0);
+            rc = fast_verify_resident_run(ctx, (const uint8_t*)d_proofs, proof_stride, k0, mc, (const uint32_t*)d_inputs,
+                                          (const uint32_t*)d_outputs, inv, S.CP, S.d_mini, canon.data() + k0, stv.data() + k0);
+            if (rc != STARK_OK) return rc;
+        }
+    } else if (use_fast && (rc = fast_classify_resident(ctx, (const uint8_t*)d_proofs, proof_stride, n_proofs, canon.data())) != STARK_OK) {
         return rc;
+    }
     std::vector<uint64_t> bases;
     std::vector<uint32_t> who;
     std::vector<size_t> rest;
     for (size_t i = 0; i < n_proofs; i++) {
+        if (one_pass) {
+            if (!canon[i]) rest.push_back(i);
+            continue;
+        }
         if (canon[i]) {
             bases.push_back(proof_stride * i);
             who.push_back((uint32_t)i);

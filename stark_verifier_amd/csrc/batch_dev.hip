@@ -338,10 +338,12 @@ struct InvArg {
 };
 __global__ void __launch_bounds__(64)
 vio_kernel(const uint32_t* __restrict__ inputs, const uint32_t* __restrict__ outputs, const uint32_t* __restrict__ who, uint32_t m,
-           InvArg inv_last_m1, uint32_t* __restrict__ io) {
+           InvArg inv_last_m1, uint32_t* __restrict__ io, uint64_t first, uint64_t stride, uint64_t* __restrict__ base_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
-    const size_t i = who[k];
+    // selected proof k is proof who[k], or proof first + k of a run (which then also gets its byte offset written)
+    const size_t i = who ? (size_t)who[k] : (size_t)(first + k);
+    if (base_out) base_out[k] = stride * i;
     const F29 in = fio::norm(fio::load_limbs(inputs + 8 * i)), out = fio::norm(fio::load_limbs(outputs + 8 * i));
     Fe c;
 #pragma unroll
@@ -750,8 +752,50 @@ int fast_make_io(stark_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_out
     hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
     InvArg a;
     memcpy(a.l, inv_last_m1, 32);
-    hipLaunchKernelGGL(vio_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, st, d_inputs, d_outputs, d_who, (uint32_t)mc, a, d_io);
+    hipLaunchKernelGGL(vio_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, st, d_inputs, d_outputs, d_who, (uint32_t)mc, a, d_io,
+                       (uint64_t)0, (uint64_t)0, (uint64_t*)nullptr);
     F_TRY(hipGetLastError());
+    return STARK_OK;
+}
+
+// Proofs first .. first + mc of a device-resident array in one go, without asking first which of them have the fixed
+// structure: the structure words are compared (canonical_out[k] = 1 where they match) and the checks are run on every
+// proof, then both answers come back in one copy. status_out[k] means something only where canonical_out[k] is 1; the
+// caller sends the others through the general path. Running the fast path's kernels on a proof of another structure is
+// safe: every offset they read at comes from the fixed instance's template, none from the proof, and all lie inside
+// the first proof_size <= stride bytes.
+int fast_verify_resident_run(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t first, size_t mc,
+                             const uint32_t* d_inputs, const uint32_t* d_outputs, const uint32_t inv_last_m1[8],
+                             const CheckParams& CP, const uint32_t* d_mini, uint8_t* canonical_out, uint8_t* status_out) {
+    if (mc == 0) return STARK_OK;
+    if (stride < tmpl().proof_size || stride % 4 != 0) {
+        memset(canonical_out, 0, mc);
+        return STARK_OK;
+    }
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+    DevTemplate* D;
+    int rc = get_dev_template(ctx, &D);
+    if (rc != STARK_OK) return rc;
+    uint8_t *d = nullptr, *d_ans = nullptr;
+    if ((rc = kept_buffer(ctx, D, 3, up(8 * mc) + up(64 * mc), &d)) != STARK_OK) return rc;
+    if ((rc = kept_buffer(ctx, D, 2, 2 * up(mc), &d_ans)) != STARK_OK) return rc;
+    uint64_t* d_base = (uint64_t*)d;
+    uint32_t* d_io = (uint32_t*)(d + up(8 * mc));
+    InvArg a;
+    memcpy(a.l, inv_last_m1, 32);
+    hipLaunchKernelGGL(vio_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, st, d_inputs, d_outputs, (const uint32_t*)nullptr,
+                       (uint32_t)mc, a, d_io, (uint64_t)first, stride, d_base);
+    hipLaunchKernelGGL(vclassify_kernel, dim3((unsigned)mc), dim3(256), 0, st, d_proofs + stride * first, stride, D->words,
+                       D->n_words, d_ans);
+    F_TRY(hipGetLastError());
+    if ((rc = fast_launch(ctx, D, d_proofs, d_base, d_io, mc, CP, d_mini, st, d_ans + up(mc))) != STARK_OK) return rc;
+    // both answers in one copy
+    std::vector<uint8_t> host(2 * up(mc));
+    F_TRY(hipMemcpyAsync(host.data(), d_ans, 2 * up(mc), hipMemcpyDeviceToHost, st));
+    F_TRY(hipStreamSynchronize(st));
+    memcpy(canonical_out, host.data(), mc);
+    memcpy(status_out, host.data() + up(mc), mc);
     return STARK_OK;
 }
 

@@ -175,6 +175,9 @@ int fast_session_piece(stark_ctx* ctx, FastSession* s, const uint64_t* bases, co
 int fast_session_end(stark_ctx* ctx, FastSession* s, uint8_t* status_out);
 // structure check of device-resident proofs at d_proofs + i * stride; canonical_out is a host array
 int fast_resident_scratch(stark_ctx* ctx, size_t bytes, uint8_t** out);
+int fast_verify_resident_run(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t first, size_t mc,
+                             const uint32_t* d_inputs, const uint32_t* d_outputs, const uint32_t inv_last_m1[8],
+                             const CheckParams& CP, const uint32_t* d_mini, uint8_t* canonical_out, uint8_t* status_out);
 int fast_classify_resident(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t stride, size_t n, uint8_t* canonical_out);
 // d_io[k] = (canonical input, slope) of proof d_who[k] from device-resident n x 8-limb inputs / outputs
 int fast_make_io(stark_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_outputs, const uint32_t* d_who, size_t mc,

@@ -161,6 +161,11 @@ def test_prove_and_verify_without_leaving_the_device(monkeypatch):
     monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
     a_g, s_g = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in2.data_ptr(), 8192, consts, d_out.data_ptr())
     assert np.array_equal(a, a_g) and np.array_equal(s, s_g)
+    # asking for the structure first and checking the matching proofs only (the default queues both at once)
+    monkeypatch.delenv("STARKHIP_BATCH_PATH")
+    monkeypatch.setenv("STARKHIP_BATCH_RESIDENT", "twostep")
+    a_t, s_t = batch.verify_mimc_batch_dev(d_proofs.data_ptr(), stride, n, d_in2.data_ptr(), 8192, consts, d_out.data_ptr())
+    assert np.array_equal(a, a_t) and np.array_equal(s, s_t)
 
 
 @pytest.mark.gpu

@@ -11,3 +11,12 @@ d=json.loads(sys.stdin.readline())
 print('batch %.0f /s  resident %.0f /s (%.3f ms)  parity %s' % (d['batch_verify']['value'], d['batch_verify']['device_resident_value'], d['batch_verify']['device_resident_ms_per_step'], all(d['parity'].values())))"
 done
 done
+for rep in 1 2 3; do
+for v in twostep onepass; do
+  echo "== resident $v"
+  STARKHIP_BATCH_RESIDENT=$v timeout -k 5 100 python bench.py --steps 10 --warmup 3 --ntt-batch 4 --cfg2-batch 0 --sharded-log-n 0 --no-cpu-baseline --merkle-n 65536 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('batch %.0f /s  resident %.0f /s (%.3f ms)  parity %s' % (d['batch_verify']['value'], d['batch_verify']['device_resident_value'], d['batch_verify']['device_resident_ms_per_step'], all(d['parity'].values())))"
+done
+done
