@@ -168,14 +168,16 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // registers. Where four elements and prefetched table entries are alive (the twiddle multiplications of a round, the
     // inter-pass table) the kinds that already fill the 128 registers of four wavefronts per SIMD (passes that
     // prefetch an inter-pass table, the folded inverse) would spill with it (the compiler's resource report) and use
-    // it in the low columns only, where it costs none; at 1024-point tiles the first and middle passes do have the
-    // registers (with the scheduling option this file is built with, see the Makefile). The multiplication by the 4th
+    // it in the low columns only, where it costs none; which instantiations those are is read off the compiler's
+    // resource report (with the scheduling option this file is built with, see the Makefile): the folded inverse, first
+    // and middle passes at 64- and 256-point tiles, some sizes of the general kernel. The multiplication by the 4th
     // root of unity comes when the twiddles are dead and has the registers in every kind.
 #ifdef STARKHIP_MULW
     constexpr int MULW_TW = STARKHIP_MULW & 3, MULW = MULW_TW, MULW_U = STARKHIP_MULW >> 2;
 #else
-    constexpr int MULW_TW = (((KIND == KIND_FIRST || KIND == KIND_MID) && LOGT != 10) || KIND == KIND_FOLD || (KIND == KIND_GENERAL && LOGT == 10)) ? 2 : 3;
-    constexpr int MULW = MULW_TW, MULW_U = 3;
+    constexpr bool tight = KIND == KIND_FOLD || ((KIND == KIND_FIRST || KIND == KIND_MID) && (LOGT <= 6 || LOGT == 8)) ||
+                           (KIND == KIND_GENERAL && (LOGT == 5 || LOGT == 7 || LOGT == 10 || LOGT == 11));
+    constexpr int MULW_TW = tight ? 2 : 3, MULW = MULW_TW, MULW_U = 3;
 #endif
     const bool in_raw = (KIND == KIND_FIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
     const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.out_raw != 0;
