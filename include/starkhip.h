@@ -341,8 +341,10 @@ int stark_field_op(stark_ctx* ctx, int op, const uint32_t* a, const uint32_t* b,
 /* stark_mimc_verify_batch_io with diagnostic switches, for tests that compare the verifier's paths and its scalar
  * checks against a restatement of src/lib.rs:31-197 one check at a time. flags is a sum of:
  *   STARK_DIAG_IGNORE_MERKLE      a Merkle mismatch (status 4) is not recorded, so the scalar checks decide alone:
- *                                 proofs with damaged values reach statuses 5..8. Disables a soundness check: never
- *                                 use outside tests.
+ *                                 proofs with damaged values reach statuses 5..8. Disables a soundness check, so it
+ *                                 exists only in the test build of the library (compiled with -DSTARKHIP_DIAG into
+ *                                 libstarkhip_diag.so, `make diag`); libstarkhip.so returns STARK_ERR_UNSUPPORTED
+ *                                 and verifies nothing when the flag is set.
  *   STARK_DIAG_HOST_FIELD_CHECKS  the scalar checks run on host threads in the reference's own formulation
  *                                 (Lagrange interpolation, modular division) instead of the device kernels
  *   STARK_DIAG_GENERAL_PATH       every proof is parsed on the host (no device-side fast path) */

@@ -140,14 +140,17 @@ def fold_column(values, root_of_unity, special_x, p=P):
     return col
 
 
-def prove_low_degree(values, root_of_unity, maxdeg_plus_1, exclude, p=P):
-    """FRI layers as (root2, column tree, ys, poly tree, positions) plus the final values."""
+def prove_low_degree(values, root_of_unity, maxdeg_plus_1, exclude, p=P, tree=None, fold_fault=None):
+    """FRI layers as (root2, column branches, poly branches) plus the final values. `tree` is the tree of `values`
+    when the caller has built it already; `fold_fault` = (layer, slot): see mk_mimc_proof_faulty."""
     layers = []
-    m = merkelize([x.to_bytes(32, "big") for x in values])
+    m = tree or merkelize([x.to_bytes(32, "big") for x in values])
     while maxdeg_plus_1 > 16:
         special_x = int.from_bytes(m[1], "big") % p
         column = fold_column(values, root_of_unity, special_x, p)
         m2 = merkelize([x.to_bytes(32, "big") for x in column])
+        if fold_fault is not None and fold_fault[0] == len(layers):
+            _grind_fold_fault(column, m2, fold_fault[1], exclude, fold_fault[2], p)
         ys = get_pseudorandom_indices(m2[1], FRI_SAMPLES, len(column), exclude)
         poly_positions = [y + len(column) * j for y in ys for j in range(4)]
         layers.append((m2[1], [branch(m2, y) for y in ys], [branch(m, x) for x in poly_positions]))
@@ -202,28 +205,133 @@ def columns(inp, steps, round_constants, p=P):
     return p_ev, d_ev, b_ev, output, G2
 
 
-def mk_mimc_proof(inp, steps, round_constants, p=P):
-    """Returns (serialized proof, output)."""
-    precision = steps * EXTENSION_FACTOR
-    p_ev, d_ev, b_ev, output, G2 = columns(inp, steps, round_constants, p)
-    mtree = merkelize([a.to_bytes(32, "big") + b.to_bytes(32, "big") + c.to_bytes(32, "big")
-                       for a, b, c in zip(p_ev, d_ev, b_ev)])
-    k1, k2, k3, k4 = (int.from_bytes(blake(mtree[1] + bytes([i])), "big") for i in (1, 2, 3, 4))
+def _trace_leaves(p_ev, d_ev, b_ev):
+    return [a.to_bytes(32, "big") + b.to_bytes(32, "big") + c.to_bytes(32, "big") for a, b, c in zip(p_ev, d_ev, b_ev)]
+
+
+def _linear_combination(p_ev, d_ev, b_ev, trace_root, G2, steps, p=P):
+    """L = D + k1 P + k2 P x^steps + k3 B + k4 B x^steps over the extended domain (src/lib.rs:131-146,190)."""
+    k1, k2, k3, k4 = (int.from_bytes(blake(trace_root + bytes([i])), "big") for i in (1, 2, 3, 4))
     g2s = pow(G2, steps, p)
     l_ev, pw = [], 1
-    for i in range(precision):
+    for i in range(len(p_ev)):
         l_ev.append((d_ev[i] + p_ev[i] * k1 + p_ev[i] * k2 * pw + b_ev[i] * k3 + b_ev[i] * pw * k4) % p)
         pw = pw * g2s % p
-    l_mtree = merkelize([x.to_bytes(32, "big") for x in l_ev])
-    positions = get_pseudorandom_indices(l_mtree[1], SPOT_CHECKS, precision, EXTENSION_FACTOR)
+    return l_ev
+
+
+def _serialize(mtree, l_mtree, layers, final, positions, precision):
     augmented = []
     for x in positions:
         augmented += [x, (x + EXTENSION_FACTOR) % precision]
-    layers, final = prove_low_degree(l_ev, G2, steps * 2, EXTENSION_FACTOR, p)
     out = [mtree[1], l_mtree[1]]
     for root2, col, poly in layers:
         out += [struct.pack("<I", 1), root2, _multiproof_bytes(col), _multiproof_bytes(poly)]
     out += [struct.pack("<II", 2, 32 * len(final))] + [x.to_bytes(32, "big") for x in final]
     out.append(_multiproof_bytes([branch(mtree, x) for x in augmented]))
     out.append(_multiproof_bytes([branch(l_mtree, x) for x in positions]))
-    return b"".join(out), output
+    return b"".join(out)
+
+
+def mk_mimc_proof(inp, steps, round_constants, p=P):
+    """Returns (serialized proof, output)."""
+    precision = steps * EXTENSION_FACTOR
+    p_ev, d_ev, b_ev, output, G2 = columns(inp, steps, round_constants, p)
+    mtree = merkelize(_trace_leaves(p_ev, d_ev, b_ev))
+    l_ev = _linear_combination(p_ev, d_ev, b_ev, mtree[1], G2, steps, p)
+    l_mtree = merkelize([x.to_bytes(32, "big") for x in l_ev])
+    positions = get_pseudorandom_indices(l_mtree[1], SPOT_CHECKS, precision, EXTENSION_FACTOR)
+    layers, final = prove_low_degree(l_ev, G2, steps * 2, EXTENSION_FACTOR, p, tree=l_mtree)
+    return _serialize(mtree, l_mtree, layers, final, positions, precision), output
+
+
+# ---- a malicious prover (test infrastructure) -------------------------------------------------------------------
+# Proofs whose trees are all consistent (every ProofBranch::verify succeeds, src/merkle_tree.rs:119-171) but whose
+# committed data is wrong at exactly one sampled place, so that exactly one of the scalar asserts the reference reaches
+# after the branches (src/lib.rs:85,181,187,190) fails. What is sampled depends on the roots, which depend on the data,
+# so the fault is ground in: a free value is varied, only its path of the tree rehashed, until the sampler
+# (src/utils.rs:53-94) puts the wrong value at the wanted place of the wanted index set.
+
+def _set_leaf(nodes, index, leaf):
+    """Replaces the leaf of natural index `index` and rehashes its path; returns the new root."""
+    L = len(nodes) // 2
+    ld4 = L // 4
+    pos = L + index // ld4 + 4 * (index % ld4)
+    nodes[pos] = leaf
+    pos >>= 1
+    while pos:
+        nodes[pos] = blake(nodes[2 * pos] + nodes[2 * pos + 1])
+        pos >>= 1
+    return nodes[1]
+
+
+def _index_at(seed, slot, modulus, exclude):
+    """get_pseudorandom_indices(seed, ..)[slot], hashing only as far as that entry needs."""
+    data = seed
+    for _ in range(slot // 8):
+        data = blake(data)
+    x = int.from_bytes(data[4 * (slot % 8):4 * (slot % 8) + 4], "big") % (modulus * (exclude - 1) // exclude)
+    return 1 + x + x // (exclude - 1)
+
+
+def _grind(nodes, leaf_index, leaf_of, target, slot, count, modulus, exclude, limit=4_000_000):
+    """Varies leaf `leaf_index` = leaf_of(t), t = 1, 2, .., until index set `count` drawn from the root holds `target`
+    at `slot` and nowhere else. Returns t."""
+    for t in range(1, limit):
+        root = _set_leaf(nodes, leaf_index, leaf_of(t))
+        if _index_at(root, slot, modulus, exclude) != target:
+            continue
+        if get_pseudorandom_indices(root, count, modulus, exclude).count(target) == 1:
+            return t
+    raise RuntimeError("no tweak found")
+
+
+def _grind_fold_fault(column, m2, slot, exclude, where, p):
+    """column[i] becomes a value the fold does not give, with i = entry `slot` of the layer's own sample."""
+    i = where % len(column)
+    i += (i % exclude == 0)          # multiples of `exclude` are never sampled
+    true = column[i]
+    t = _grind(m2, i, lambda t: ((true + t) % p).to_bytes(32, "big"), i, slot, FRI_SAMPLES, len(column), exclude)
+    column[i] = (true + t) % p
+
+
+def mk_mimc_proof_faulty(inp, steps, round_constants, fault, where=12345, p=P, base=None):
+    """A proof whose every Merkle branch verifies and whose data is wrong in exactly one sampled place.
+
+    fault = ("fold", layer, slot): the column committed at FRI layer `layer` differs from the fold of the previous
+                                   layer at the row the verifier samples as entry `slot` (src/lib.rs:85);
+            ("D", slot) / ("B", slot): the D / B value in the trace tree is wrong at the spot-check position drawn as
+                                   entry `slot`, L computed from the wrong value (src/lib.rs:181 / :187);
+            ("L", slot):           the committed L differs from the linear combination there (src/lib.rs:190).
+    `where` picks the domain index that carries the fault. `base` = columns(inp, steps, round_constants) when the caller
+    makes several proofs of one instance. Returns (serialized proof, output, index of the fault)."""
+    precision = steps * EXTENSION_FACTOR
+    p_ev, d_ev, b_ev, output, G2 = base or columns(inp, steps, round_constants, p)
+    kind = fault[0]
+    i = where % precision
+    i += (i % EXTENSION_FACTOR == 0)
+    if kind in ("D", "B"):
+        d_ev, b_ev = list(d_ev), list(b_ev)
+        col = d_ev if kind == "D" else b_ev
+        col[i] = (col[i] + 1) % p
+    mtree = merkelize(_trace_leaves(p_ev, d_ev, b_ev))
+    l_ev = _linear_combination(p_ev, d_ev, b_ev, mtree[1], G2, steps, p)
+    l_mtree = merkelize([x.to_bytes(32, "big") for x in l_ev])
+    fold_fault = None
+    if kind in ("D", "B"):
+        # L(0) is free: position 0 is a multiple of the extension factor, which neither the spot checks nor the first
+        # FRI layer's rows ever open, and the column of that layer is folded from whatever L the tree holds
+        true = l_ev[0]
+        t = _grind(l_mtree, 0, lambda t: ((true + t) % p).to_bytes(32, "big"), i, fault[1], SPOT_CHECKS, precision, EXTENSION_FACTOR)
+        l_ev[0] = (true + t) % p
+    elif kind == "L":
+        true = l_ev[i]
+        t = _grind(l_mtree, i, lambda t: ((true + t) % p).to_bytes(32, "big"), i, fault[1], SPOT_CHECKS, precision, EXTENSION_FACTOR)
+        l_ev[i] = (true + t) % p
+    elif kind == "fold":
+        fold_fault = (fault[1], fault[2], where)
+    else:
+        raise ValueError(fault)
+    positions = get_pseudorandom_indices(l_mtree[1], SPOT_CHECKS, precision, EXTENSION_FACTOR)
+    layers, final = prove_low_degree(l_ev, G2, steps * 2, EXTENSION_FACTOR, p, tree=l_mtree, fold_fault=fold_fault)
+    return _serialize(mtree, l_mtree, layers, final, positions, precision), output, i

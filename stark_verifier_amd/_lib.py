@@ -54,17 +54,30 @@ class InvalidArgument(StarkError, ValueError):
 
 
 _lib = None
+_other_libs = {}
 
 
 def load() -> ctypes.CDLL:
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = load_from(LIB_PATH)
+    return _lib
+
+
+def load_from(path: str) -> ctypes.CDLL:
+    """Another build of the library under its own handle (the tests' libstarkhip_diag.so); pass it to Context(lib=...)."""
+    path = os.path.abspath(path)
+    if path not in _other_libs:
+        _other_libs[path] = _bind(path)
+    return _other_libs[path]
+
+
+def _bind(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C stark_verifier_amd/csrc` "
+            f"{path} is missing: build it with `make -C stark_verifier_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, sz, u32, u64, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
     L.stark_version.restype = i32
     L.stark_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
@@ -137,15 +150,14 @@ def load() -> ctypes.CDLL:
     L.stark_mimc_prove_batch.restype = i32
     L.stark_mimc_prove_batch_dev.argtypes = [vp, vp, sz, u64, vp, sz, vp, u64, vp, vp]
     L.stark_mimc_prove_batch_dev.restype = i32
-    _lib = L
     return L
 
 
 class Context:
     """Owns one ``stark_ctx`` (device buffers, stream, cached twiddle tables)."""
 
-    def __init__(self, device: int = 0):
-        self._lib = load()
+    def __init__(self, device: int = 0, lib: ctypes.CDLL | None = None):
+        self._lib = lib or load()
         h = ctypes.c_void_p()
         rc = self._lib.stark_ctx_create(device, ctypes.byref(h))
         if rc != STARK_OK:

@@ -566,9 +566,11 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
     // where the scalar checks run: on the device unless STARKHIP_BATCH_FIELD=host (equivalent paths)
     const char* fenv = getenv("STARKHIP_BATCH_FIELD");
     S.field_on_host = (fenv && strcmp(fenv, "host") == 0) || (flags & STARK_DIAG_HOST_FIELD_CHECKS);
-    // test only, reachable through stark_mimc_verify_batch_diag alone: the scalar checks decide even when a branch
-    // mismatched, so damaged values exercise every check
+#ifdef STARKHIP_DIAG
+    // test build only (libstarkhip_diag.so), through stark_mimc_verify_batch_diag alone: the scalar checks decide even
+    // when a branch mismatched, so damaged values exercise every check. The shipped library has no such switch.
     S.skip_merkle = (flags & STARK_DIAG_IGNORE_MERKLE) != 0;
+#endif
     const char* menv = getenv("STARKHIP_BATCH_MERKLE");
     S.force_flatten = menv && strcmp(menv, "flatten") == 0;
     const char* penv = getenv("STARKHIP_BATCH_PATH");
@@ -1091,12 +1093,24 @@ extern "C" int stark_mimc_verify_batch_io(stark_ctx* ctx, const uint8_t* proofs,
     return verify_impl(ctx, proofs, offsets, n_proofs, inputs, outputs, 8, num_steps, round_constants, n_constants, accept, status);
 } STARK_CATCH
 
-// Test support: stark_mimc_verify_batch_io with diagnostic switches (STARK_DIAG_*). The only way to make the
-// verifier overlook a Merkle mismatch; nothing in the library calls it.
+// Test support: stark_mimc_verify_batch_io with diagnostic switches (STARK_DIAG_*); nothing in the library calls it.
+// The switch that makes the verifier overlook a Merkle mismatch exists only in the test build (-DSTARKHIP_DIAG,
+// libstarkhip_diag.so): the shipped library refuses it.
 extern "C" int stark_mimc_verify_batch_diag(stark_ctx* ctx, const uint8_t* proofs, const uint64_t* offsets, size_t n_proofs,
                                             const uint32_t* inputs, uint64_t num_steps, const uint32_t* round_constants,
                                             size_t n_constants, const uint32_t* outputs, unsigned flags, uint8_t* accept,
                                             uint8_t* status) try {
+    if (!ctx) return STARK_ERR_INVALID;
+    if (flags & ~(STARK_DIAG_IGNORE_MERKLE | STARK_DIAG_HOST_FIELD_CHECKS | STARK_DIAG_GENERAL_PATH)) {
+        ctx_set_error(ctx, "stark_mimc_verify_batch_diag: unknown flag");
+        return STARK_ERR_INVALID;
+    }
+#ifndef STARKHIP_DIAG
+    if (flags & STARK_DIAG_IGNORE_MERKLE) {
+        ctx_set_error(ctx, "STARK_DIAG_IGNORE_MERKLE is honoured by the test build of the library only (libstarkhip_diag.so)");
+        return STARK_ERR_UNSUPPORTED;
+    }
+#endif
     return verify_impl(ctx, proofs, offsets, n_proofs, inputs, outputs, 8, num_steps, round_constants, n_constants, accept,
                        status, flags);
 } STARK_CATCH

@@ -171,8 +171,9 @@ def _ref_status_blind(blob, inp, steps, consts, output):
     return rv.verify_mimc_proof_status(inp, steps, consts, output, proof, _merkle_blind_hooks())
 
 
-def test_scalar_checks_status_by_status_against_the_restatement(proof_bytes):
-    """With Merkle mismatches ignored (stark_mimc_verify_batch_diag; no environment variable reaches this) the scalar
+def test_scalar_checks_status_by_status_against_the_restatement(proof_bytes, diag_ctx):
+    """With Merkle mismatches ignored (stark_mimc_verify_batch_diag of the test build of the library; the shipped
+    library refuses the flag and no environment variable reaches it) the scalar
     checks alone decide, so damaged values exercise every one of them. Expected status = the first failing step of the
     Python restatement of src/lib.rs:31-197 run with a MultiProof::verify that checks nothing; the device kernels
     (fast path and general path) and the host formulation must all report exactly that."""
@@ -205,7 +206,7 @@ def test_scalar_checks_status_by_status_against_the_restatement(proof_bytes):
     ins, outs = [3] * n, [output] * n
     blind = batch.DIAG_IGNORE_MERKLE
     for flags in (blind | batch.DIAG_GENERAL_PATH, blind | batch.DIAG_HOST_FIELD_CHECKS):
-        a, s = batch.verify_mimc_batch_diag(blobs, ins, 8192, consts, outs, flags)
+        a, s = batch.verify_mimc_batch_diag(blobs, ins, 8192, consts, outs, flags, ctx=diag_ctx)
         assert np.array_equal(s, expect), (flags, [(i, int(x), int(y)) for i, (x, y) in enumerate(zip(s, expect)) if x != y])
         assert np.array_equal(a, (expect == 0).astype(np.uint8))
     # the same proofs through the production entry point: every damaged one is a Merkle mismatch first
@@ -213,11 +214,34 @@ def test_scalar_checks_status_by_status_against_the_restatement(proof_bytes):
     assert a[0] == 1 and not a[1:].any() and set(s[1:].tolist()) == {4}
 
 
+def test_shipped_library_refuses_to_overlook_merkle_mismatches(proof_bytes, diag_ctx):
+    """STARK_DIAG_IGNORE_MERKLE switches a soundness check off: libstarkhip.so answers STARK_ERR_UNSUPPORTED and writes
+    no verdict; only tests/libstarkhip_diag.so honours it. The other two switches choose between equivalent paths and
+    work in both builds."""
+    from stark_verifier_amd import _lib, batch
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    bad = bytearray(proof_bytes)
+    bad[proofio.value_offsets(proof_bytes)["lincomb", 0] + 3] ^= 4
+    blobs = [proof_bytes, bytes(bad)]
+    for flags in (batch.DIAG_IGNORE_MERKLE, batch.DIAG_IGNORE_MERKLE | batch.DIAG_GENERAL_PATH, 7):
+        with pytest.raises(_lib.StarkError) as e:
+            batch.verify_mimc_batch_diag(blobs, [3, 3], 8192, consts, [output] * 2, flags)
+        assert e.value.code == _lib.STARK_ERR_UNSUPPORTED
+    with pytest.raises(_lib.InvalidArgument):
+        batch.verify_mimc_batch_diag(blobs, [3, 3], 8192, consts, [output] * 2, 8)
+    for flags in (0, batch.DIAG_GENERAL_PATH, batch.DIAG_HOST_FIELD_CHECKS):
+        a, s = batch.verify_mimc_batch_diag(blobs, [3, 3], 8192, consts, [output] * 2, flags)
+        assert list(a) == [1, 0] and list(s) == [0, 4]
+    a, s = batch.verify_mimc_batch_diag(blobs, [3, 3], 8192, consts, [output] * 2, batch.DIAG_IGNORE_MERKLE, ctx=diag_ctx)
+    assert list(a) == [1, 0] and list(s) == [0, 8]
+
+
 def _put_at(blob, off, new):
     return blob[:off] + new + blob[off + len(new):]
 
 
-def test_column_value_at_or_above_p_is_rejected_like_the_reference(proof_bytes):
+def test_column_value_at_or_above_p_is_rejected_like_the_reference(proof_bytes, diag_ctx):
     """src/lib.rs:85 compares eval_quartic(...) (reduced) with BigInt::from_bytes_be(column value) (not reduced): a
     column value encoded as v + p never matches, although it is the same field element. Four equal rows make the
     interpolated cubic the constant v, so the lane's evaluation is v; the column value is then v (accepted by the
@@ -241,7 +265,7 @@ def test_column_value_at_or_above_p_is_rejected_like_the_reference(proof_bytes):
     n = len(blobs)
     blind = batch.DIAG_IGNORE_MERKLE
     for flags in (blind | batch.DIAG_GENERAL_PATH, blind | batch.DIAG_HOST_FIELD_CHECKS):
-        a, s = batch.verify_mimc_batch_diag(blobs, [3] * n, 8192, consts, [output] * n, flags)
+        a, s = batch.verify_mimc_batch_diag(blobs, [3] * n, 8192, consts, [output] * n, flags, ctx=diag_ctx)
         assert list(s) == expect, (flags, list(s))
     a, s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)      # production: Merkle mismatch either way
     assert not a.any() and set(s.tolist()) == {4}
