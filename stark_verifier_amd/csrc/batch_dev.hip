@@ -169,26 +169,20 @@ struct DevTemplate : CtxAttachment {
     // of resident proofs
     uint8_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t buf_bytes[4] = {0, 0, 0, 0};
-    // pipelined host path: kernels of piece k run on `compute` while piece k + 1 is on the link (the context's stream);
-    // `pinned` carries the per-proof offsets and inputs up and the verdicts down without a blocking pageable copy
+    // pipelined host path: kernels of piece k run on `compute` (auxiliary stream 0 of the context) while piece k + 1 is
+    // on the link (the context's main stream); `pinned` carries the per-proof offsets and inputs up and the verdicts
+    // down without a blocking pageable copy
     hipStream_t compute = nullptr;
     uint8_t* pinned = nullptr;
     size_t pinned_bytes = 0;
-    // the scalar checks of a call run on `side` beside its branch launch (fork after the samples, join before the
-    // verdicts): they are short, latency-bound launches that fill the gaps of the long one
+    // the scalar checks of a call run on `side` (auxiliary stream 1 of the context) beside its branch launch (fork
+    // after the samples, join before the verdicts): they are short, latency-bound launches that fill the gaps of the
+    // long one. Both streams belong to the context, which drains and destroys them.
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~DevTemplate() override {
-        if (side) {
-            (void)hipStreamSynchronize(side);
-            (void)hipStreamDestroy(side);
-        }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (compute) {
-            (void)hipStreamSynchronize(compute);
-            (void)hipStreamDestroy(compute);
-        }
         if (pinned) (void)hipHostFree(pinned);
         (void)hipFree(branches);
         (void)hipFree(fri);
@@ -502,8 +496,13 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     const bool overlap = !(getenv("STARKHIP_BATCH_OVERLAP") && atoi(getenv("STARKHIP_BATCH_OVERLAP")) == 0);
     hipStream_t sc = st;
     if (overlap) {
-        // (a plain stream: with a high-priority one, calls of 1,250 proofs stopped making progress on this system)
-        if (!D->side) F_TRY(hipStreamCreateWithFlags(&D->side, hipStreamNonBlocking));
+        // A plain stream of the context (ctx_aux_stream gives the rules). The fork event is recorded on st before side
+        // is told to wait for it, the join event on side before st is; the call before this one on st ended with its
+        // own join, so side is idle when the fork lands and one pair of events serves every call. (An earlier version
+        // gave these launches a high-priority stream, after which calls of 1,250 proofs made no progress. No trace of
+        // a stuck call was kept, so the cause is not established; the one thing that differed was this wait, a
+        // high-priority queue waiting for an upload and a sampling kernel queued at normal priority.)
+        if (!D->side) F_TRY(ctx_aux_stream(ctx, 1, &D->side));
         if (!D->ev_fork) F_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
         if (!D->ev_join) F_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
         F_TRY(hipEventRecord(D->ev_fork, st));
@@ -602,7 +601,7 @@ int fast_session_begin(stark_ctx* ctx, const uint8_t* chunk, const size_t* cuts,
     int rc = get_dev_template(ctx, &S->D);
     if (rc != STARK_OK) return rc;
     DevTemplate* D = S->D;
-    if (!D->compute) F_TRY(hipStreamCreateWithFlags(&D->compute, hipStreamNonBlocking));
+    if (!D->compute) F_TRY(ctx_aux_stream(ctx, 0, &D->compute));
     const size_t pin_need = up(8 * max_proofs) + up(64 * max_proofs) + up(max_proofs);
     if (D->pinned_bytes < pin_need) {
         F_TRY(hipStreamSynchronize((hipStream_t)stark_ctx_stream(ctx)));

@@ -78,7 +78,7 @@ struct stark_ctx {
         bool tried = false;
         std::unique_ptr<WorkerPool> pool;  // the host threads that fill or drain the buffers
     } up, down;
-    hipStream_t stream2 = nullptr, stream3 = nullptr;  // transform and download streams of the pipelined host path
+    hipStream_t aux[starkhip::CTX_AUX_STREAMS] = {};  // ctx_aux_stream: the only other streams the library creates
     unsigned copy_threads = 8;
 };
 
@@ -189,6 +189,32 @@ void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a) {
     if (ctx && slot >= 0 && slot < CTX_SLOTS) ctx->attach[slot].reset(a);
 }
 hipError_t ctx_make_current(stark_ctx* ctx) { return ctx ? hipSetDevice(ctx->device) : hipErrorInvalidValue; }
+
+// Auxiliary stream `which` of the context (made on first use, destroyed with the context). Rules every user keeps, so
+// that work spread over the context's streams can always drain:
+//  * plain streams, all of one priority. A wait whose waiter outranks its signaller can starve the signaller where
+//    queues are served in strict priority order (a waiting queue still counts as busy), so the library creates no
+//    priority stream at all;
+//  * an event is recorded before any stream is told to wait for it, and every wait points from work queued later to
+//    work queued earlier. The wait-for graph therefore follows host enqueue order and has no cycle, whichever hardware
+//    queue a stream lands on and whether or not two of them share one (a shared queue runs its packets in the order
+//    they were queued, which is the same order);
+//  * no kernel of the library spins on memory another kernel writes: every dependency between launches is such an
+//    event or stream order;
+//  * an entry point that used an auxiliary stream waits for it before it returns, so between calls only the main
+//    stream (and streams the caller passed in) can hold work.
+hipError_t ctx_aux_stream(stark_ctx* ctx, int which, hipStream_t* out) {
+    if (!ctx || which < 0 || which >= CTX_AUX_STREAMS) return hipErrorInvalidValue;
+    if (!ctx->aux[which]) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->aux[which], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            ctx->aux[which] = nullptr;
+            return e;
+        }
+    }
+    *out = ctx->aux[which];
+    return hipSuccess;
+}
 void ctx_set_error(stark_ctx* ctx, const char* text) {
     if (ctx) ctx->err = text ? text : "";
 }
@@ -719,8 +745,9 @@ int ntt_common(stark_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, si
 int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t batch, size_t per_group, NttPlan* plan) {
     const size_t poly_bytes = (size_t)32 << log_n, poly_words = (size_t)8 << log_n;
     const size_t groups = (batch + per_group - 1) / per_group;
-    if (!ctx->stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    hipStream_t stream2, stream3;  // transforms and downloads; the uploads take the context's main stream
+    HIP_TRY(ctx, ctx_aux_stream(ctx, 0, &stream2));
+    HIP_TRY(ctx, ctx_aux_stream(ctx, 1, &stream3));
     // the multi-pass intermediate is sized before anything is queued: growing it later would free memory in use
     if (plan->passes.size() > 1) {
         const size_t per_call = std::min(per_group, std::max<size_t>(1, ctx->chunk_bytes / poly_bytes));
@@ -769,12 +796,12 @@ int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t b
                 while (transformed.load(std::memory_order_acquire) <= g) std::this_thread::yield();
                 if (up_err.load() || down_err.load()) break;  // the main thread stopped queueing: nothing more to fetch
                 const size_t off = g * per_group * poly_words, len = count_of(g) * poly_bytes;
-                if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream3, done[g], 0);
+                if (e == hipSuccess) e = hipStreamWaitEvent(stream3, done[g], 0);
                 if (!staged_down) {
-                    if (e == hipSuccess) e = copy_d2h(ctx, limbs + off, d + off, len, ctx->stream3);
+                    if (e == hipSuccess) e = copy_d2h(ctx, limbs + off, d + off, len, stream3);
                 } else {
-                    if (e == hipSuccess) e = hipMemcpyAsync(P.buf[g & 1], d + off, len, hipMemcpyDeviceToHost, ctx->stream3);
-                    if (e == hipSuccess) e = hipEventRecord(P.ev[g & 1], ctx->stream3);
+                    if (e == hipSuccess) e = hipMemcpyAsync(P.buf[g & 1], d + off, len, hipMemcpyDeviceToHost, stream3);
+                    if (e == hipSuccess) e = hipEventRecord(P.ev[g & 1], stream3);
                 }
             }
             if (staged_down && g >= 1 && e == hipSuccess) {
@@ -793,11 +820,11 @@ int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t b
         while (uploaded.load(std::memory_order_acquire) <= g) std::this_thread::yield();
         if (rc == STARK_OK && !up_err.load()) {
             try {  // nothing may unwind past the two running threads
-                hipError_t e = hipStreamWaitEvent(ctx->stream2, up[g], 0);
+                hipError_t e = hipStreamWaitEvent(stream2, up[g], 0);
                 if (e != hipSuccess) rc = fail(ctx, STARK_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
                 uint32_t* dg = d + g * per_group * poly_words;
-                if (rc == STARK_OK) rc = run_plan(ctx, plan, dg, dg, count_of(g), ctx->stream2);
-                if (rc == STARK_OK && (e = hipEventRecord(done[g], ctx->stream2)) != hipSuccess)
+                if (rc == STARK_OK) rc = run_plan(ctx, plan, dg, dg, count_of(g), stream2);
+                if (rc == STARK_OK && (e = hipEventRecord(done[g], stream2)) != hipSuccess)
                     rc = fail(ctx, STARK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
             } catch (...) {
                 rc = STARK_ERR_NOMEM;
@@ -809,7 +836,7 @@ int ntt_host_pipelined(stark_ctx* ctx, uint32_t* limbs, unsigned log_n, size_t b
     uploader.join();
     downloader.join();
     ctx->copy_threads = saved_threads;
-    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->stream2), e3 = hipStreamSynchronize(ctx->stream3);
+    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(stream2), e3 = hipStreamSynchronize(stream3);
     drop_events();
     if (rc != STARK_OK) return rc;
     if (up_err.load()) return fail(ctx, STARK_ERR_HIP, "staged upload: %s", hipGetErrorString((hipError_t)up_err.load()));
@@ -1133,6 +1160,8 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t a : ctx->aux)
+        if (a) (void)hipStreamSynchronize(a);
     for (auto& a : ctx->attach) a.reset();
     for (auto& p : ctx->plans) free_plan(p.get());
     for (auto& p : ctx->shard_tables) free_plan(p.get());
@@ -1146,8 +1175,8 @@ void stark_ctx_destroy(stark_ctx* ctx) {
             if (P->buf[i]) (void)hipHostFree(P->buf[i]);
             if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
         }
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    for (hipStream_t a : ctx->aux)
+        if (a) (void)hipStreamDestroy(a);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

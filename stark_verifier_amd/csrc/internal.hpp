@@ -22,6 +22,14 @@ void ctx_set_attachment(stark_ctx* ctx, int slot, CtxAttachment* a);
 void ctx_set_error(stark_ctx* ctx, const char* text);
 // makes the context's device the calling thread's current device (every entry point does this first)
 hipError_t ctx_make_current(stark_ctx* ctx);
+// Every stream the library ever creates belongs to a context: its main stream (stark_ctx_stream) and at most
+// CTX_AUX_STREAMS auxiliary ones, made on first use and shared by everything that overlaps work inside one call (the
+// pipelined host paths of the transforms and of the batch verifier, the scalar checks beside the branch launch, the
+// prover's download). With the caller's own stream that is four software streams per context at most, the number of
+// hardware queues a process gets here (GPU_MAX_HW_QUEUES), so no two of them have to share a queue. All are plain
+// streams of equal priority; see ctx_aux_stream in capi.hip for the rules their users keep.
+constexpr int CTX_AUX_STREAMS = 2;
+hipError_t ctx_aux_stream(stark_ctx* ctx, int which, hipStream_t* out);
 
 // Copies between ordinary (pageable) host memory and the device through two pinned staging buffers of the context:
 // host threads fill or drain one while the DMA engine moves the other (about twice the rate of a direct copy from

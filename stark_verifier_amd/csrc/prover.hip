@@ -876,20 +876,19 @@ extern "C" int stark_mimc_prove_batch(stark_ctx* ctx, const uint32_t* inputs, si
     if (B > 256) B = 256;
     struct Res {
         uint8_t* d = nullptr;
-        hipStream_t cs = nullptr;
+        hipStream_t cs = nullptr;  // the download stream: auxiliary stream 1 of the context
         hipEvent_t ev[2] = {nullptr, nullptr};
         ~Res() {
             if (cs) (void)hipStreamSynchronize(cs);
             (void)hipFree(d);
             for (hipEvent_t e : ev)
                 if (e) (void)hipEventDestroy(e);
-            if (cs) (void)hipStreamDestroy(cs);
         }
     } R;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_out = up(n * 32), o_b0 = 2 * o_out, o_b1 = o_b0 + up(B * psz);
     P_TRY(hipMalloc((void**)&R.d, o_b1 + up(B * psz)));
-    P_TRY(hipStreamCreateWithFlags(&R.cs, hipStreamNonBlocking));
+    P_TRY(ctx_aux_stream(ctx, 1, &R.cs));
     for (hipEvent_t& e : R.ev) P_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     P_TRY(hipMemcpyAsync(R.d, inputs, n * 32, hipMemcpyHostToDevice, st));
     uint8_t* bufs[2] = {R.d + o_b0, R.d + o_b1};

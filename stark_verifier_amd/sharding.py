@@ -50,12 +50,15 @@ def gather_accept_bits(local_accept, total: int, device=None):
     width = (total + world - 1) // world
     padded = torch.zeros(width, dtype=torch.uint8, device=t.device)
     padded[: t.numel()] = t
-    parts = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
+    # one collective into one buffer and one copy to the host (a list of per-rank tensors costs a copy and a
+    # synchronisation per rank)
+    flat = torch.empty(world * width, dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(flat, padded)
+    host = flat.cpu().numpy().reshape(world, width)
     out = np.empty(total, dtype=np.uint8)
-    for r, p in enumerate(parts):
+    for r in range(world):
         lo, hi = shard_range(total, r, world)
-        out[lo:hi] = p[: hi - lo].cpu().numpy()
+        out[lo:hi] = host[r, : hi - lo]
     return out
 
 
