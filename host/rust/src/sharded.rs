@@ -39,7 +39,7 @@ unsafe extern "C" fn all_to_all(user: *mut c_void, d_send: *const c_void, d_recv
 
 /// d_x: this rank's "rows" slice [n1 / world][n2] of x (element (a, j2) = x[(rank * n1 / world + a) + n1 * j2]), n / world
 /// elements of 32 bytes, overwritten; d_y: a second buffer of the same size. The "columns" slice of the result,
-/// [n1][n2 / world] with element (k1, b) = X[k1 * n2 + rank * n2 / world + b], is left in d_y (in d_x when world == 1).
+/// [n1][n2 / world] with element (k1, b) = X[k1 * n2 + rank * n2 / world + b], is left in d_y (the exchange runs on a one-rank communicator too).
 pub fn ntt_sharded(d_x: *mut c_void, d_y: *mut c_void, log_n: u32, rank: usize, ex: &Exchange, root: &[u32; 8], inverse: bool) {
     let rc = ffi::CTX.with(|c| unsafe {
         ffi::stark_ntt_sharded_dev(*c, d_x, d_y, log_n, ex.world as u32, rank as u32, root.as_ptr(), inverse as c_int,

@@ -167,8 +167,9 @@ int stark_ntt_sharded_stage_c_dev(stark_ctx* ctx, const void* d_recv, void* d_ou
 typedef int (*stark_all_to_all_fn)(void* user, const void* d_send, void* d_recv, size_t block_bytes, void* stream);
 
 /* Stage A, exchange(user, ...), stage C in one call. d_x holds the "rows" input and is overwritten; d_y is the other
- * n / world element buffer. The "columns" result is left in d_y when world > 1 and in d_x when world == 1 (no
- * exchange is called then). Queued on `stream` (NULL = the context's stream); does not synchronise. */
+ * n / world element buffer. `exchange` is called whenever it is not NULL (also with world == 1, where a one-rank
+ * communicator moves the single block to itself) and must be given when world > 1. The "columns" result is left in
+ * d_y when an exchange ran and in d_x otherwise. Queued on `stream` (NULL = the context's stream); does not synchronise. */
 int stark_ntt_sharded_dev(stark_ctx* ctx, void* d_x, void* d_y, unsigned log_n, unsigned world, unsigned rank,
                           const uint32_t root_of_unity[8], int inverse, stark_all_to_all_fn exchange, void* user,
                           void* stream);

@@ -1117,14 +1117,16 @@ int stark_ntt_sharded_dev(stark_ctx* ctx, void* d_x, void* d_y, unsigned log_n, 
     void* st = stream ? stream : (void*)ctx->stream;
     int rc = stark_ntt_sharded_stage_a_dev(ctx, d_x, d_y, log_n, world, rank, root_of_unity, inverse, st);
     if (rc != STARK_OK) return rc;
-    const void* recv = d_y;  // one rank: the send blocks are the received ones
-    if (world > 1) {
+    // An exchange function runs whenever one is given, also on a single rank (a one-rank communicator then moves the
+    // one block to itself); without one the send blocks of the single rank are the received ones.
+    const void* recv = d_y;
+    if (exchange) {
         const size_t block = (((size_t)1 << log_n) / world / world) * 32;
         if (exchange(user, d_y, d_x, block, st) != 0) return fail(ctx, STARK_ERR_HIP, "the exchange function reported a failure");
         recv = d_x;
     }
     // stage C is out of place: from the received blocks into the other buffer
-    return stark_ntt_sharded_stage_c_dev(ctx, recv, world > 1 ? d_y : d_x, log_n, world, root_of_unity, inverse, st);
+    return stark_ntt_sharded_stage_c_dev(ctx, recv, exchange ? d_y : d_x, log_n, world, root_of_unity, inverse, st);
 } STARK_CATCH
 
 

@@ -370,3 +370,19 @@ def test_all_ranks_in_one_process_stage_by_stage(log_n, world, split, monkeypatc
             assert rc == _lib.STARK_ERR_UNSUPPORTED
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_c_host_drives_the_exchange_with_rccl_send_recv():
+    """host/test_rccl_exchange.c: a plain C host builds a one-rank RCCL communicator and passes the grouped
+    ncclSend / ncclRecv all-to-all of the binding example to stark_ntt_sharded_dev (where it runs although world is 1)
+    and issues it itself between the two stage calls; 2^16 and 2^24 points, forward and inverse, byte-identical to
+    stark_ntt_batch_dev."""
+    import subprocess
+    exe = os.path.join(ROOT, "host", "test_rccl_exchange")
+    if not os.path.exists(exe):
+        pytest.fail("host/test_rccl_exchange is not built (make -C stark_verifier_amd/csrc host)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("byte-identical") == 4
