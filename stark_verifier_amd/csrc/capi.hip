@@ -47,6 +47,10 @@ struct NttPlan {
     uint64_t cols = 0;        // column plans: columns of the matrix; stage A tables: world << 32 | rank
     size_t table_bytes = 0;   // device memory held by `tables`
     uint64_t last_use = 0;    // for least-recently-used eviction
+    // two passes of 1024-point tiles: the streaming kernels (ntt29.hip) take them unless a call overrides the last pass;
+    // the last pass then applies the inter-pass factors, row k1 of the table holding w^(k1 * j) for its m inputs
+    const uint32_t* stream_tw = nullptr;
+    uint64_t stream_m = 0;
 };
 
 }  // namespace
@@ -79,6 +83,10 @@ struct stark_ctx {
         std::unique_ptr<WorkerPool> pool;  // the host threads that fill or drain the buffers
     } up, down;
     hipStream_t aux[starkhip::CTX_AUX_STREAMS] = {};  // ctx_aux_stream: the only other streams the library creates
+    // work counters of the streaming transform kernels: one block of 8 per stream that ever launched them (launches on
+    // one stream run in order and zero the block in between; launches on different streams must not share one)
+    std::vector<std::pair<hipStream_t, uint32_t*>> tickets;
+    int n_cu = 0;  // compute units of the device
     unsigned copy_threads = 8;
 };
 
@@ -510,6 +518,11 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             set_quarter_root(a, w2, l2);
             p.tiles = (unsigned)(n1 >> a.log_c);
             plan->passes.push_back(p);
+            if (tiled_mid && l1 == 10 && l2 == 10 && plan->passes[0].args.log_c == 1 && a.log_c == 1 &&
+                env_int("STARKHIP_STREAM", 1) != 0) {
+                plan->stream_tw = TW1;
+                plan->stream_m = m;
+            }
         } else {
             const int l2 = split[1], l3 = split[2];
             const uint64_t n2 = (uint64_t)1 << l2, n3 = (uint64_t)1 << l3;
@@ -702,6 +715,28 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.outP = a.poly_stride;
             a.ksh = 31;
             a.kmask = 0xFFFFFFFFu;
+            // The streaming kernels pay from a few work items per resident workgroup on (below that nothing is left to
+            // fetch ahead, and zeroing the counters is a launch of its own); calls that override the last pass and the
+            // allocation-free entry point keep to the plain kernels.
+            if (plan->stream_tw && !ov && !fixed &&
+                (uint64_t)p.tiles * cnt >= (uint64_t)env_int("STARKHIP_STREAM_MIN", 4) * ntt29_stream_resident(ctx->n_cu)) {
+                uint32_t* tk = nullptr;
+                for (auto& t : ctx->tickets)
+                    if (t.first == stream) tk = t.second;
+                if (!tk) {
+                    HIP_TRY(ctx, hipMalloc((void**)&tk, 256));
+                    ctx->tickets.emplace_back(stream, tk);
+                }
+                a.tickets = tk;
+                a.stream = 1;
+                if (k == 1) {
+                    a.TW = plan->stream_tw;
+                    a.twP = a.twA = 0;
+                    a.twB = plan->stream_m << a.log_c;
+                    a.twC = plan->stream_m;
+                    a.twS = 1;
+                }
+            }
             if (ov && k + 1 == plan->passes.size()) {
                 // the last pass stores output index o = k1 + n1' * k (outS = n1'); the split point 2^ksh of o is at or
                 // above n1' (checked by the caller), so it splits k alone
@@ -1150,6 +1185,11 @@ int stark_ctx_create(int device, stark_ctx** out) try {
         delete ctx;
         return STARK_ERR_HIP;
     }
+    if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cu <= 0) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return STARK_ERR_HIP;
+    }
     const char* cb = getenv("STARKHIP_CHUNK_MB");
     if (cb && atoi(cb) > 0) ctx->chunk_bytes = (size_t)atoi(cb) << 20;
     const char* tb = getenv("STARKHIP_TABLE_MB");
@@ -1171,6 +1211,7 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     for (auto& p : ctx->stage_a_tabs) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
+    for (auto& t : ctx->tickets) (void)hipFree(t.second);
     for (stark_ctx::PinPair* P : {&ctx->up, &ctx->down})
         for (int i = 0; i < 2; i++) {
             if (P->busy[i]) (void)hipEventSynchronize(P->ev[i]);  // a transfer on a caller's stream

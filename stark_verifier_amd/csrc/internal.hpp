@@ -86,6 +86,12 @@ struct NttPassArgs {
     // multiplications per lane: Wlast = W with every entry times the factor (the three twiddled inputs; entry 0, the
     // factor itself, multiplies the fourth input).
     const uint32_t* Wlast;
+    // 1: the streaming form of a two-pass plan at 1024-point tiles (ntt29.hip, kinds 7 and 8): the first pass leaves the
+    // inter-pass factors to the last pass, whose TW / tw* fields then address them by input row and element
+    uint32_t stream;
+    // streaming form: eight work counters (one per XCD) in device memory, owned by the caller and used by one launch at
+    // a time; the launcher zeroes them on the launch's stream
+    uint32_t* tickets;
 };
 
 // W entries are 12 unpacked dwords
@@ -93,6 +99,8 @@ size_t ntt29_pass_lds_bytes(int log_t, int log_c);
 // bytes per element of the multi-pass intermediate (nine unpacked limbs)
 size_t ntt29_mid_bytes();
 hipError_t launch_ntt29_pass(int log_t, const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream);
+// workgroups the streaming form of a pass keeps resident on a device of n_cu compute units
+unsigned ntt29_stream_resident(int n_cu);
 hipError_t launch_unpack_table(const uint32_t* in, uint32_t* out, size_t count, hipStream_t stream);
 // ---- tables.hip ----
 // n = 1 or 2 (no radix-4 round exists): out = transform(in), one lane per polynomial

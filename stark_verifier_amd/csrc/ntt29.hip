@@ -29,6 +29,7 @@
 #include "internal.hpp"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace starkhip {
 
@@ -133,15 +134,24 @@ struct Quad29 {
 };
 
 #ifdef STARKHIP_STAMPS
-// timing instrumentation (debug builds only): wave 0 of every workgroup records the 100 MHz
-// wall clock at the end of each phase
-__device__ unsigned long long g_stamps[2][8192][16];
-#define STAMP(i)                                                                          \
-    do {                                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[in_raw ? 1 : 0][blockIdx.x][i] = wall_clock64(); \
+// timing instrumentation (debug builds only): lane 0 of every wavefront records the 100 MHz wall clock at entry (0) and,
+// per round r, once its inputs are in registers (1 + 3r, after waiting for them), once its outputs are computed and
+// handed to LDS or memory (2 + 3r) and once the exchange is synchronised or the stores have drained (3 + 3r); slots 16
+// and 17 hold the hardware's wavefront placement (HW_ID, XCC_ID)
+__device__ unsigned long long g_stamps[2][8192][8][24];
+#define STAMP(i)                                                                                              \
+    do {                                                                                                      \
+        if ((threadIdx.x & 63u) == 0 && item < 8192)                                                          \
+            g_stamps[in_raw ? 1 : 0][item][(threadIdx.x >> 6) & 7u][i] = wall_clock64();                      \
+    } while (0)
+#define STAMPW(i)                           \
+    do {                                    \
+        __builtin_amdgcn_s_waitcnt(0);      \
+        STAMP(i);                           \
     } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMPW(i) do {} while (0)
 #endif
 
 // KIND: instantiations for the shapes that carry the load, with their flags known at compile time (fewer scalar
@@ -156,11 +166,25 @@ __device__ unsigned long long g_stamps[2][8192][16];
 //   6 single pass, no output factor: packed on both sides, element index fastest, no table
 // Kinds 1, 2, 4, 5 (the passes of multi-pass plans) also know that every tile of the grid exists and how many tiles a
 // workgroup takes; all but 0 know that the output index is not split.
-constexpr int KIND_GENERAL = 0, KIND_FIRST = 1, KIND_LAST = 2, KIND_FOLD = 3, KIND_MID = 4, KIND_LAST3 = 5, KIND_SINGLE = 6;
+//   7, 8 "streaming" first and last pass of two at 1024-point tiles: a fixed grid of resident workgroups, each walking
+//     through work items blockIdx.x, blockIdx.x + gridDim.x, ...; the next item's input is fetched straight into LDS
+//     (global_load_lds, no registers) while the last round of the current item computes and stores, so that no
+//     wavefront waits for global memory at the start of an item (see "landing" below). That costs a workgroup barrier
+//     after the last round's LDS reads (the image must be dead before the fetch is queued) and, in kind 8, two around
+//     the reads of round 0. Kind 7 leaves the inter-pass factors to kind 8, which multiplies by them as it reads its
+//     input: a last round then issues no load after the fetch (loads return in order, so a table entry requested
+//     behind the fetch would wait for it).
+constexpr int KIND_GENERAL = 0, KIND_FIRST = 1, KIND_LAST = 2, KIND_FOLD = 3, KIND_MID = 4, KIND_LAST3 = 5, KIND_SINGLE = 6,
+              KIND_SFIRST = 7, KIND_SLAST = 8;
+
+typedef __attribute__((address_space(3))) void* lds_dma_dst_t;
+typedef __attribute__((address_space(1))) const void* lds_dma_src_t;
 
 template <int LOGT, int KIND>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
-    constexpr bool MULTI = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3;
+    constexpr bool STREAM = KIND == KIND_SFIRST || KIND == KIND_SLAST;
+    static_assert(!STREAM || LOGT == 10, "the landing layout of the streaming kinds is laid out for two 1024-point tiles per workgroup");
+    constexpr bool MULTI = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3 || STREAM;
     constexpr bool ONE = KIND == KIND_FOLD || KIND == KIND_SINGLE;
     constexpr bool SPECIAL = MULTI || ONE;
     constexpr bool FOLD = KIND == KIND_FOLD;
@@ -179,8 +203,8 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
                            (KIND == KIND_GENERAL && (LOGT == 5 || LOGT == 7 || LOGT == 10 || LOGT == 11));
     constexpr int MULW_TW = tight ? 2 : 3, MULW = MULW_TW, MULW_U = 3;
 #endif
-    const bool in_raw = (KIND == KIND_FIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
-    const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.out_raw != 0;
+    const bool in_raw = (KIND == KIND_FIRST || KIND == KIND_SFIRST || ONE) ? false : MULTI ? true : a.in_raw != 0;
+    const bool out_raw = (KIND == KIND_FIRST || KIND == KIND_MID || KIND == KIND_SFIRST) ? true : SPECIAL ? false : a.out_raw != 0;
     const bool load_cfast = (KIND == KIND_LAST3 || ONE) ? false : MULTI ? true : a.load_cfast != 0;
     const bool store_cfast = ONE ? false : MULTI ? true : a.store_cfast != 0;
     const bool has_tw = (KIND == KIND_FIRST || KIND == KIND_MID) ? true : SPECIAL ? false : a.TW != nullptr;
@@ -194,24 +218,34 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // the special kinds also fix the tiles per workgroup at what the planner picks for this tile size (512 lanes)
     const uint32_t log_c = MULTI ? (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0) : a.log_c, C = 1u << log_c;
     const uint32_t Tp = G::ROW + tile_pad29(log_c);
-    const uint32_t tid = threadIdx.x;
+    uint32_t tid = threadIdx.x;  // (re-read opaquely per item by the streaming kinds, see the item loop)
     const uint32_t in_w = in_raw ? RAW_W : 8u, out_w = out_raw ? RAW_W : 8u;
     // Work item -> (tile, polynomial). Workgroups are dealt round-robin over the 8 XCDs, each with
     // its own L2. With the grouped order, the workgroups that share an L2 take 2^grp_log adjacent
     // tiles (whose strided 64..96-byte pieces complete each other's 128-byte lines) of every
     // polynomial in turn (which re-use the same rows of the inter-pass twiddle table), while the
     // chip as a whole still sweeps memory front to back.
-    uint32_t tau, pidx;
-    if (a.grp_log) {
-        const uint32_t g = a.grp_log - 1, xcd = blockIdx.x & 7u, s = blockIdx.x >> 3, s2 = s >> g;
-        pidx = s2 % a.polys;
-        tau = ((((s2 / a.polys) << 3) | xcd) << g) | (s & ((1u << g) - 1u));
-    } else {
-        tau = blockIdx.x % a.tiles;
-        pidx = blockIdx.x / a.tiles;
-    }
-    const uint32_t hi = tau >> a.dsh, lo = tau & a.dmask;
-    const uint64_t poly = (uint64_t)pidx * a.poly_stride;
+    auto decode = [&](uint32_t item, uint32_t& tau_, uint32_t& pidx_) {
+        if (a.grp_log) {
+            const uint32_t g = a.grp_log - 1, xcd = item & 7u, s = item >> 3, s2 = s >> g;
+            pidx_ = s2 % a.polys;
+            tau_ = ((((s2 / a.polys) << 3) | xcd) << g) | (s & ((1u << g) - 1u));
+        } else {
+            tau_ = item % a.tiles;
+            pidx_ = item / a.tiles;
+        }
+    };
+    uint32_t item = blockIdx.x;  // the streaming kinds go on to item + gridDim.x, ... below
+    const uint32_t items = STREAM ? a.tiles * a.polys : 0u;
+    uint32_t tau, pidx, hi, lo;
+    uint64_t poly;
+    auto set_item = [&](uint32_t it) {
+        decode(it, tau, pidx);
+        hi = tau >> a.dsh;
+        lo = tau & a.dmask;
+        poly = (uint64_t)pidx * a.poly_stride;
+    };
+    set_item(item);
 
     // LDS slot of position p of tile c (an element occupies nine dwords at slot * 9)
     auto at = [&](uint32_t c, uint32_t p) -> uint32_t {
@@ -244,6 +278,18 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // global -> registers for the lane's four inputs (first round; zeros for tiles past the end)
     auto load_inputs = [&](uint32_t c, uint32_t j, bool valid) -> Quad29 {
         F29 x0, x1, x2, x3;
+#ifdef STARKHIP_ABL_NOLOAD
+        if (valid) {  // timing-only build: inputs made up in registers, no global load
+#pragma unroll
+            for (int l = 0; l < 9; l++) {
+                x0.l[l] = (j * 2654435761u + l * 40503u + c) & F29_MASK;
+                x1.l[l] = (x0.l[l] * 3u + hi + lo) & F29_MASK;
+                x2.l[l] = (x1.l[l] * 5u + pidx) & F29_MASK;
+                x3.l[l] = (x2.l[l] * 7u + 1u) & F29_MASK;
+            }
+            return Quad29{x0, x1, x2, x3};
+        }
+#endif
         if (valid) {
             const uint32_t* src = a.in + in_w * (poly + hi * a.inA + lo * a.inB + c * a.inC);
             // offset of input j (in dwords): j * inS, or split at bit jsh of j
@@ -275,9 +321,105 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         return round != ROUNDS - 1 && local && ns_now >= (uint32_t)LW && ns_next >= (uint32_t)LW && !next_last_edge;
     };
 
+    // ---- landing (streaming kinds) ----------------------------------------------------------------------------
+    // A global_load_lds instruction deposits 4 or 16 bytes per lane at consecutive addresses from a wave-uniform LDS
+    // base (lane L at base + 4 L or 16 L), each lane naming its own global address, which need only be 4-byte aligned
+    // (measured, tools/probe/lds_dma_probe.hip). Both kinds run round 0 tile index fastest, lane (c, j) = (tid & 1,
+    // tid >> 1).
+    //   kind 7 (packed 32-byte elements, two adjacent columns). Every wavefront fetches exactly what it reads itself in
+    //     round 0, into the part of the image that only it writes in round 0; nothing else touches that part between the
+    //     barrier after the last round's LDS reads and the barrier after round 0, so the fetch needs no barrier of its
+    //     own. Lane (c, j) writes positions 4j .. 4j + 3 of tile c, i.e. slot swz(j) of sub-images 0..3, so wavefront
+    //     w (j in [32w, 32w + 32)) owns eight chunks of 32 slots = 1152 bytes at slot 32w of sub-image k of tile c, chunk
+    //     i = 4c + k. One instruction per chunk: chunk i takes rows 32w + 256 (i >> 1) + 16 (i & 1) + (0..15), four lanes
+    //     per 64-byte run; lane (c, jj = j mod 32) finds input q in chunk 2q + (jj >> 4) at byte 32 ((jj & 15) * 2 + c).
+    //   kind 8 (36-byte elements of the tiled intermediate: runs of four elements = 144 bytes = nine 16-byte pieces
+    //     holding rows c = 0, 1 at j even, odd). A wavefront's 576 pieces do not fit its own chunks in whole
+    //     instructions, so the workgroup's 512 runs land back to back from LDS byte 0 (run t = j >> 1 at 144 t, nine
+    //     instructions per wavefront) and round 0 reads element (c, j) at 144 (j >> 1) + 36 (2c + (j & 1)), between two
+    //     barriers: every wavefront's pieces have landed / every lane has read, before round 0 overwrites the image.
+    //     (Measured against a variant that keeps kind 8 free of those barriers by running round 0 element index
+    //     fastest, each wavefront fetching its own 36-byte elements as 16 + 16 + 4 bytes: 3 % slower, the fetch then
+    //     takes its runs apart.)
+    uint32_t wv = STREAM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) : 0u, ln = tid & 63u;
+    auto chunk = [&](uint32_t i) -> uint32_t { return ((i >> 2) * Tp + (i & 3u) * G::SB + 32u * wv) * 9u; };  // dword index
+    auto issue_landing = [&](uint32_t it) {
+        uint32_t tau2, pidx2;
+        decode(it, tau2, pidx2);
+        [[maybe_unused]] const uint64_t base = (uint64_t)pidx2 * a.poly_stride + (uint64_t)(tau2 >> a.dsh) * a.inA + (uint64_t)(tau2 & a.dmask) * a.inB;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (KIND == KIND_SFIRST) {
+            const uint64_t rs = a.inS * 32;  // bytes between rows
+            const char* g = reinterpret_cast<const char*>(a.in) + 32 * base + (uint64_t)(32u * wv + (ln >> 2)) * rs + (ln & 3u) * 16u;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++)
+                __builtin_amdgcn_global_load_lds((lds_dma_src_t)(g + (uint64_t)(256u * (i >> 1) + 16u * (i & 1u)) * rs),
+                                                 (lds_dma_dst_t)(lds + chunk(i)), 16, 0, 0);
+        } else if (KIND == KIND_SLAST) {
+            const uint32_t rs = (uint32_t)a.inS2 * 36u;  // bytes between runs (the last run starts below 2^32)
+            const char* g = reinterpret_cast<const char*>(a.in) + 36 * base;
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) {
+                const uint32_t piece = (wv * 9u + i) * 64u + ln, t = (piece * 7282u) >> 16, part = piece - 9u * t;  // t = piece / 9
+                __builtin_amdgcn_global_load_lds((lds_dma_src_t)(g + ((uint64_t)t * rs + part * 16u)),
+                                                 (lds_dma_dst_t)(lds + (wv * 9u + i) * 256u), 16, 0, 0);
+            }
+        }
+#endif
+    };
+    // the lane's four inputs from the landing (round 0 of a streaming kind), lane (c, j) = (tid & 1, tid >> 1)
+    auto landed_inputs = [&]() -> Quad29 {
+        F29 x[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            if (KIND == KIND_SFIRST) {
+                const uint32_t jj = ln >> 1, cc = ln & 1u;
+                const uint4* p4 = reinterpret_cast<const uint4*>(lds + chunk(2 * q + (jj >> 4)) + 8u * (((jj & 15u) << 1) + cc));
+                const uint4 u0 = p4[0], u1 = p4[1];
+                Fe f;
+                f.l[0] = u0.x; f.l[1] = u0.y; f.l[2] = u0.z; f.l[3] = u0.w;
+                f.l[4] = u1.x; f.l[5] = u1.y; f.l[6] = u1.z; f.l[7] = u1.w;
+                x[q] = f29_from_fe(f);
+            } else {
+                const uint32_t jq = (tid >> 1) + q * Q;
+                const uint32_t* p1 = lds + 36u * (jq >> 1) + 9u * (2u * (ln & 1u) + (jq & 1u));
+#pragma unroll
+                for (int l = 0; l < 9; l++) x[q].l[l] = p1[l];
+            }
+        }
+        return Quad29{x[0], x[1], x[2], x[3]};
+    };
+    // Which item a streaming workgroup takes next: not item + gridDim.x. The two workgroups of a compute unit do not
+    // advance at the same rate (the older wavefronts win the issue arbitration, and resident workgroups never change
+    // age: one was measured at 28 us per item beside one at 70), so equal shares would leave half of the chip waiting
+    // for the other half. Instead every XCD has a ticket counter (a.tickets[xcd], zeroed before the launch): a
+    // workgroup's first item is its own index, every further one ticket * 8 + xcd, drawn by thread 0 at the start of the
+    // last round and handed to the other wavefronts through the LDS word behind the image. It is drawn a round early
+    // because the fetch of the next item is queued in the last round; a workgroup that draws a ticket past the end
+    // fetches its current item once more (nobody reads it), so that the number of fetch instructions is fixed.
+    constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
+    uint32_t nxt = NO_ITEM;
+    const uint32_t lds_next = C * Tp * 9u;  // dword index of the hand-over word
+
     constexpr bool ODD = (LOGT & 1) != 0;
+    if (STREAM) issue_landing(item);
+    do {  // one pass for every kind but the streaming ones
+    if (STREAM) {
+        // everything a lane derives from its index is worked out again per item: kept across items (the compiler hoists
+        // it out of the loop) it fills registers that the last round then spills, and a reload from scratch there would
+        // wait behind the fetch
+        asm volatile("" : "+v"(tid));
+        ln = tid & 63u;
+        wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    }
     uint32_t ns_log = 0;
     STAMP(0);
+#ifdef STARKHIP_STAMPS
+    if ((threadIdx.x & 63u) == 0 && item < 8192) {
+        g_stamps[in_raw ? 1 : 0][item][(threadIdx.x >> 6) & 7u][16] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_stamps[in_raw ? 1 : 0][item][(threadIdx.x >> 6) & 7u][17] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     if (ODD) {
         // odd log2(T): one radix-2 level first, on tight inputs; outputs stay lazy (limbs < 3 * 2^29)
         uint32_t c, j;
@@ -294,9 +436,11 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         else __syncthreads();
         ns_log = 1;
     }
-#pragma unroll 1
-    for (int round = ODD ? 1 : 0; round < ROUNDS; round++) {
-        const bool first = !ODD && round == 0, last = round == ROUNDS - 1;
+    // One round. The streaming kinds instantiate it three times (first, middle, last round, the flags compile-time
+    // constants): with one body for all rounds the compiler cannot tell that the fetch queued in a last round has been
+    // waited for before the middle rounds and puts a wait for all outstanding loads in front of every LDS access there.
+    auto do_round = [&](auto first_, auto last_, int round) __attribute__((always_inline)) {
+        const bool first = first_, last = last_;
         // which lane order this round runs in
         bool local;
         uint32_t c, j;
@@ -323,8 +467,55 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         const bool folded = FOLD && last && ns_log > 0;
         const uint32_t* Wt = folded ? a.Wlast : a.W;
         if (ns_log > 0) tw1 = f29_load_raw(Wt + 12 * (size_t)e);
+        // a streaming kind's last round requests all three twiddles here: once the next item's fetch is queued, any
+        // later load would come back behind it
+        F29 tw2, tw3;
+        uint32_t ticket = 0;
+        if (STREAM && last) {
+            tw2 = f29_load_raw(Wt + 12 * (size_t)(2 * e));
+            tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
+            // The draw, by thread 0 alone. Written out so that nothing waits for it here: inside a branch the compiler
+            // waits for the returned value where the branch ends; this way the value is first looked at behind the
+            // wait for all loads below, a round of LDS reads later. (exec is narrowed to thread 0 of wavefront 0 and
+            // empty in the other wavefronts, where the instruction then does nothing.)
+            const uint64_t only0 = __ballot(tid == 0);
+            uint64_t saved_exec;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "s_mov_b64 exec, %[m]\n\t"
+                "global_atomic_add %[d], %[off], %[one], %[base] sc0\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [d] "=&v"(ticket), [sv] "=&s"(saved_exec)
+                : [m] "s"(only0), [off] "v"((blockIdx.x & 7u) * 4u), [one] "v"(1u), [base] "s"(a.tickets)
+                : "memory");
+        }
         F29 x0, x1, x2, x3;
-        if (first) {
+        if (STREAM && first) {
+            // kind 8 multiplies its inputs by the inter-pass factors w^(k1 * j) (row k1 = lo * C + c, contiguous in j)
+            // (requesting them for the next item behind the last round's arithmetic instead was measured: no gain)
+            Fe t0, t1, t2, t3;
+            if (KIND == KIND_SLAST) {
+                const uint32_t* tw = a.TW + 8 * (pidx * a.twP + hi * a.twA + lo * a.twB + c * a.twC);
+                t0 = fe_load(tw + 8 * ((uint64_t)j * a.twS));
+                t1 = fe_load(tw + 8 * ((uint64_t)(j + Q) * a.twS));
+                t2 = fe_load(tw + 8 * ((uint64_t)(j + 2 * Q) * a.twS));
+                t3 = fe_load(tw + 8 * ((uint64_t)(j + 3 * Q) * a.twS));
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's landing (and the item before's stores)
+            if (KIND == KIND_SLAST) __syncthreads();  // ... and every other wavefront's
+            const Quad29 q = landed_inputs();
+            if (KIND == KIND_SLAST) __syncthreads();  // all read before round 0 writes over the landing
+            x0 = q.a;
+            x1 = q.b;
+            x2 = q.c;
+            x3 = q.d;
+            if (KIND == KIND_SLAST) {
+                x0 = f29_mul<MULW>(x0, f29_from_fe(t0));
+                x1 = f29_mul<MULW>(x1, f29_from_fe(t1));
+                x2 = f29_mul<MULW>(x2, f29_from_fe(t2));
+                x3 = f29_mul<MULW>(x3, f29_from_fe(t3));
+            }
+        } else if (first) {
             const Quad29 q = load_inputs(c, j, valid);
             x0 = q.a;
             x1 = q.b;
@@ -337,21 +528,39 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             x3 = lds_get29(lds, at(c, j + 3 * Q));
         }
         const bool out_local = exchange_is_local(round, local, ns_log, ns_log + 2);
+        STAMPW(1 + 3 * round);
         if (!first) {
             // inputs are in registers. If other wavefronts will overwrite them (cross-wave exchange)
             // every wavefront must have finished reading first; a wave-local exchange only needs the
             // compiler to keep this wavefront's own LDS order.
             if (out_local) __builtin_amdgcn_wave_barrier();
             else if (!last) __syncthreads();
+            else if (STREAM) {
+                // every wavefront holds its inputs: the image is dead, and the next item's input may land in it
+                // The round's twiddles must be in before the fetch is queued: the compiler answers any wait for a load
+                // with a wait for every outstanding load while a global_load_lds is in flight (it cannot tell which LDS
+                // bytes that one writes), so nothing may be waited for between here and the next item. The scheduling
+                // barriers keep the fetch where it is written: ahead of the round's arithmetic.
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                if (tid == 0) {
+                    const uint32_t t = ticket + (gridDim.x >> 3);
+                    lds[lds_next] = t < (items >> 3) ? 8u * t + (blockIdx.x & 7u) : NO_ITEM;
+                }
+                __syncthreads();
+                nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[lds_next]);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_landing(nxt == NO_ITEM ? item : nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         if (ns_log > 0) {
             // the three twiddled inputs come out of the multiplier tight; the untwiddled one is brought
             // back to 29-bit limbs by a carry pass. Each later twiddle is requested one multiplication
             // ahead of its use.
-            F29 tw2 = f29_load_raw(Wt + 12 * (size_t)(2 * e));
+            if (!(STREAM && last)) tw2 = f29_load_raw(Wt + 12 * (size_t)(2 * e));
             x1 = f29_mul<MULW_TW>(x1, tw1);
-            F29 tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
+            if (!(STREAM && last)) tw3 = f29_load_raw(Wt + 12 * (size_t)(3 * e));
             x2 = f29_mul<MULW_TW>(x2, tw2);
             x3 = f29_mul<MULW_TW>(x3, tw3);
             if (folded) x0 = f29_mul<MULW_TW>(x0, f29_load_raw(Wt));  // entry 0 of the scaled table is the factor itself
@@ -406,9 +615,10 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
         if (!last) {
             lds_put29(lds, at(c, d + (1u << ns_log)), y1);
             lds_put29(lds, at(c, d + (3u << ns_log)), y3);
+            STAMP(2 + 3 * round);
             if (out_local) __builtin_amdgcn_wave_barrier();
             else __syncthreads();  // the next round's inputs come from other wavefronts
-            STAMP(1 + round);
+            STAMP(3 + 3 * round);
         } else if (valid) {
             if (!has_tw && has_scale && !folded) {
                 Fe s;
@@ -439,12 +649,25 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
             }
         }
         ns_log += 2;
+    };
+    if (STREAM) {
+        do_round(std::true_type{}, std::false_type{}, 0);
+#pragma unroll 1
+        for (int round = 1; round < ROUNDS - 1; round++) do_round(std::false_type{}, std::false_type{}, round);
+        do_round(std::false_type{}, std::true_type{}, ROUNDS - 1);
+    } else {
+#pragma unroll 1
+        for (int round = ODD ? 1 : 0; round < ROUNDS; round++) do_round(!ODD && round == 0, round == ROUNDS - 1, round);
     }
+    STAMP(2 + 3 * (ROUNDS - 1));
 #ifdef STARKHIP_STAMPS
-    STAMP(ROUNDS);
-    __builtin_amdgcn_s_waitcnt(0);
-    STAMP(ROUNDS + 1);
+    STAMPW(3 + 3 * (ROUNDS - 1));
 #endif
+    if (!STREAM) break;
+    item = nxt;
+    if (item == NO_ITEM) break;
+    set_item(item);
+    } while (true);
 }
 
 #ifdef STARKHIP_STAMPS
@@ -452,6 +675,14 @@ extern "C" int stark_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
 #endif
+
+// How many workgroups of a streaming kind stay resident on a device of n_cu compute units: two per unit (LDS), a
+// multiple of the 8 XCDs so that a work item and the workgroup that takes it share an L2.
+unsigned ntt29_stream_resident(int n_cu) {
+    static const int per_cu = getenv("STARKHIP_STREAM_WGS") ? atoi(getenv("STARKHIP_STREAM_WGS")) : 2;
+    unsigned r = ((unsigned)(n_cu * (per_cu > 0 ? per_cu : 2)) / 8u) * 8u;
+    return r < 8 ? 8 : r;
+}
 
 template <int LOGT, int KIND>
 static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned polys, hipStream_t stream) {
@@ -489,7 +720,23 @@ static hipError_t launch_one29(const NttPassArgs& a, unsigned tiles, unsigned po
             break;
         }
     if ((uint64_t)tiles * polys >= (1ull << 31)) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((ntt29_pass_kernel<LOGT, KIND>), dim3(tiles * polys), dim3(threads), lds, stream, b);
+    unsigned grid = tiles * polys;
+    if (KIND == KIND_SFIRST || KIND == KIND_SLAST) {
+        static std::atomic<int> cus[64];
+        int n_cu = dev < 64 ? cus[dev].load(std::memory_order_acquire) : 0;
+        if (n_cu == 0) {
+            e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e != hipSuccess) return e;
+            if (dev < 64) cus[dev].store(n_cu, std::memory_order_release);
+        }
+        const unsigned resident = ntt29_stream_resident(n_cu);
+        if (grid > resident) grid = resident;
+        lds += 16;  // the hand-over word behind the image
+        if (lds > 160 * 1024 || !b.tickets) return hipErrorInvalidConfiguration;
+        e = hipMemsetAsync(b.tickets, 0, 8 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((ntt29_pass_kernel<LOGT, KIND>), dim3(grid), dim3(threads), lds, stream, b);
     return hipGetLastError();
 }
 
@@ -508,6 +755,13 @@ static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned
         }
         // (with an output table and a split output index, stage A of a sharded transform: its own instantiation was 2 %
         // slower than the general kernel at 2^12 points, 128 registers against 123)
+    }
+    if (a.stream) {  // the planner sets this only for the shapes the streaming kinds are written for
+        constexpr bool S = LOGT == 10;
+        if (!S || a.log_c != 1 || !a.load_cfast || !a.store_cfast || a.ksh != 31 || a.c_limit != ~0ull || a.has_scale || tiles % 8u)
+            return hipErrorInvalidConfiguration;
+        if (!a.in_raw) return launch_one29<LOGT, (S ? KIND_SFIRST : KIND_GENERAL)>(g, tiles, polys, stream);
+        return launch_one29<LOGT, (S ? KIND_SLAST : KIND_GENERAL)>(g, tiles, polys, stream);
     }
     if (special && LOGT >= 6 && !a.has_scale && a.store_cfast && a.ksh == 31 && a.c_limit == ~0ull &&
         a.log_c == (uint32_t)(LOGT <= 11 ? 11 - LOGT : 0)) {  // multi-pass plans in their usual shape

@@ -1,0 +1,135 @@
+"""The streaming form of the two-pass transform at 2^20 points (resident workgroups that fetch the next work item
+straight into LDS while the current one finishes, work handed out by per-XCD counters) against the plain kernels and
+the oracle: same bytes for every batch size, both directions, in and out of place, on the context's own stream and on
+a stream of the caller's, and twice in a row in one context (the counters are zeroed per launch).
+
+What is transformed follows the reference's _fft / fft_inv (src/fft.rs:37-86): out[i] = sum_j v[j] w^(ij) mod p,
+canonical residues, scaled by n^-1 for the inverse."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+P = oracle.P
+LOG_N = 20
+N = 1 << LOG_N
+W = pow(7, (P - 1) >> LOG_N, P)
+
+
+def _ctx(stream_on, **env):
+    import stark_verifier_amd as sv
+    old = {k: os.environ.get(k) for k in ["STARKHIP_STREAM", *env]}
+    os.environ["STARKHIP_STREAM"] = "1" if stream_on else "0"
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    ctx = sv.Context(0)
+    return ctx, old
+
+
+def _restore(old):
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _fill(ctx, count, seed):
+    t = torch.empty((count, 8), dtype=torch.int32, device="cuda")
+    ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, t.data_ptr(), count, seed, None))
+    ctx.synchronize()
+    return t
+
+
+def _run(ctx, x, batch, inverse, in_place=False, stream=None):
+    from stark_verifier_amd import fft
+    y = x.clone() if in_place else torch.empty_like(x)
+    torch.cuda.synchronize()  # the copy runs on torch's stream, the transform on the library's
+    src = y if in_place else x
+    if stream is None:
+        fft.ntt_batch_dev(src.data_ptr(), y.data_ptr(), LOG_N, batch, W, inverse, ctx)
+        ctx.synchronize()
+    else:
+        fft.ntt_batch_dev(src.data_ptr(), y.data_ptr(), LOG_N, batch, W, inverse, ctx, stream=stream.cuda_stream)
+        stream.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("batch", [1, 7, 8, 11, 24])
+def test_streaming_and_plain_kernels_give_the_same_bytes(batch):
+    # batch 1 and 7 stay below the streaming threshold (plain kernels in both contexts), 8 is the first size above it
+    plain, old = _ctx(False)
+    try:
+        x = _fill(plain, batch * N, 100 + batch)
+        ref_f = _run(plain, x, batch, False)
+        ref_i = _run(plain, x, batch, True)
+        plain.close()
+        fast, _ = _ctx(True)
+        for _ in range(2):  # twice: the work counters of the first run must not leak into the second
+            assert torch.equal(_run(fast, x, batch, False), ref_f)
+            assert torch.equal(_run(fast, x, batch, True), ref_i)
+        assert torch.equal(_run(fast, x, batch, False, in_place=True), ref_f)
+        assert torch.equal(_run(fast, x, batch, True, in_place=True), ref_i)
+        # a stream of the caller's (its own counters)
+        s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        assert torch.equal(_run(fast, x, batch, False, stream=s), ref_f)
+        fast.close()
+    finally:
+        _restore(old)
+    # the oracle on the first and the last polynomial
+    for b in (0, batch - 1):
+        xin = x[b * N:(b + 1) * N].cpu().numpy().view(np.uint32)
+        assert np.array_equal(ref_f[b * N:(b + 1) * N].cpu().numpy().view(np.uint32), oracle.fft_fwd(xin, W)), b
+    assert np.array_equal(ref_i[:N].cpu().numpy().view(np.uint32), oracle.fft_inv(x[:N].cpu().numpy().view(np.uint32), W))
+
+
+def test_streaming_with_every_item_count_per_workgroup():
+    # threshold 1: also the sizes where a resident workgroup gets one or two items and the counters run out at once
+    for batch in (1, 2, 3):
+        plain, old = _ctx(False)
+        try:
+            x = _fill(plain, batch * N, 7 + batch)
+            ref = _run(plain, x, batch, False)
+            plain.close()
+            fast, _ = _ctx(True, STARKHIP_STREAM_MIN=1)
+            assert torch.equal(_run(fast, x, batch, False), ref), batch
+            fast.close()
+        finally:
+            _restore(old)
+
+
+def test_streaming_with_fewer_resident_workgroups_than_the_chip_holds():
+    # one workgroup per compute unit: every workgroup walks twice as many items
+    plain, old = _ctx(False)
+    try:
+        x = _fill(plain, 8 * N, 99)
+        ref = _run(plain, x, 8, True)
+        plain.close()
+    finally:
+        _restore(old)
+    import subprocess, sys
+    # STARKHIP_STREAM_WGS is read once per process, so this case runs in a child
+    code = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import stark_verifier_amd as sv\n"
+        "from stark_verifier_amd import fft\n"
+        "ctx = sv.Context(0)\n"
+        "x = torch.empty((8 << 20, 8), dtype=torch.int32, device='cuda')\n"
+        "ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, x.data_ptr(), 8 << 20, 99, None))\n"
+        "y = torch.empty_like(x)\n"
+        "fft.ntt_batch_dev(x.data_ptr(), y.data_ptr(), 20, 8, %d, True, ctx)\n"
+        "ctx.synchronize()\n"
+        "torch.save(y.cpu(), sys.argv[1])\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), W))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "y.pt")
+        env = dict(os.environ, STARKHIP_STREAM="1", STARKHIP_STREAM_WGS="1")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        got = torch.load(out, weights_only=True)
+    assert torch.equal(got, ref.cpu())
