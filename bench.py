@@ -473,7 +473,9 @@ def main():
                        "all_ranks": bool(ok.item())},
             "roofline": {
                 "bound": "valu", "kernel": "ntt29_pass_kernel<%d>" % (log_n if passes == 1 else (log_n + 1) // 2),
-                "kernel_instantiations": "ntt29_pass_kernel<LOGT, 1> = first pass, <LOGT, 2> = last pass of two (rocprofv3 lists them separately; launch_us is the mean over both)" if passes == 2 else None,
+                "kernel_instantiations": ("ntt29_pass_kernel<LOGT, 7> = first pass, <LOGT, 8> = last pass of two in their streaming form (resident workgroups; "
+                                          "<LOGT, 1> and <LOGT, 2> are the plain form); rocprofv3 lists them separately, launch_us is the mean over both "
+                                          "and includes the launch that zeroes the work counters") if passes == 2 else None,
                 "achieved": ntt_tops, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (32-bit integer lane-ops)",
                 "frac": ntt_tops / PEAK_VALU_TOPS, "launch_us": launch_s * 1e6, "launches_per_step": launches,
                 # the same work counted in multiply-adds only, against the measured multiply-add issue rate

@@ -20,6 +20,10 @@ for d in args.dirs:
             # the instantiations of the pass kernel for one tile size (<10, 1> first pass, <10, 2> last pass, ...) are
             # reported together under the tile size alone, <10>: a launch of either moves one pass's bytes
             k = re.sub(r"(ntt29_pass_kernel<\d+), \d+>", r"\1>", r["Kernel_Name"].split("(")[0].replace("void starkhip::", ""))
+            # the Merkle kernel also runs on slices of the batch (the strong-scaling records of bench.py): only the
+            # launches over the whole batch are averaged (one lane per branch)
+            if k.startswith("merkle_verify_kernel") and int(r["Grid_Size"]) < args.merkle_n:
+                continue
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
 os.makedirs(os.path.join(root, "profiles", args.round), exist_ok=True)
