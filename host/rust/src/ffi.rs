@@ -59,11 +59,24 @@ extern "C" {
     pub fn stark_limbs_to_be32(limbs: *const u32, n: usize, be: *mut u8);
 }
 
+/// The GPU this process works on: STARKHIP_DEVICE if set, else LOCAL_RANK (one process per GPU under a launcher that
+/// shows every GPU to every rank), else 0 (also right when each rank is given one GPU through HIP_VISIBLE_DEVICES).
+pub fn device_index() -> c_int {
+    for var in ["STARKHIP_DEVICE", "LOCAL_RANK"] {
+        if let Ok(v) = std::env::var(var) {
+            if let Ok(d) = v.trim().parse::<c_int>() {
+                return d;
+            }
+        }
+    }
+    0
+}
+
 thread_local! {
-    /// One context per host thread (a context is not thread-safe), on device 0.
+    /// One context per host thread (a context is not thread-safe), on device_index().
     pub static CTX: *mut StarkCtx = unsafe {
         let mut c = std::ptr::null_mut();
-        assert_eq!(stark_ctx_create(0, &mut c), STARK_OK, "no HIP device / libstarkhip failed to start");
+        assert_eq!(stark_ctx_create(device_index(), &mut c), STARK_OK, "no HIP device / libstarkhip failed to start");
         c
     };
 }

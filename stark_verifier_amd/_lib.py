@@ -204,15 +204,18 @@ _default_ctx = {}
 
 
 def current_device() -> int:
-    """The GPU this process works on: torch's current CUDA device; for a process started by torchrun that has not
-    called torch.cuda.set_device (current device still 0), its LOCAL_RANK when the node shows that many GPUs, so that
-    the ranks of a one-process-per-GPU job do not all land on GPU 0."""
+    """The GPU this process works on. If the caller has touched torch.cuda already (torch.cuda.set_device, a tensor
+    on a device, anything that initialises it), that choice stands: torch's current device. Only a process that has
+    not, started by torchrun with every GPU visible, takes its LOCAL_RANK (when the node shows that many GPUs), so that
+    the ranks of a one-process-per-GPU job do not all land on GPU 0 by default. Callers that keep their tensors or
+    their communicator on another device than these rules give pass `device` explicitly."""
     lr = os.environ.get("LOCAL_RANK")
     if torch is not None and torch.cuda.is_available():
-        dev = torch.cuda.current_device()
-        if dev == 0 and lr is not None and lr.isdigit() and int(lr) < torch.cuda.device_count():
+        if torch.cuda.is_initialized():
+            return torch.cuda.current_device()
+        if lr is not None and lr.isdigit() and int(lr) < torch.cuda.device_count():
             return int(lr)
-        return dev
+        return torch.cuda.current_device()
     return 0
 
 

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <exception>
 #include <map>
 #include <new>
 #include <thread>
@@ -405,25 +406,43 @@ static WorkerPool& host_pool() {
 }
 static std::mutex host_pool_mutex;
 
+// An exception out of f (allocation failure in the parsers) is caught where it is thrown, on whichever thread, the
+// remaining indices are dropped, and the first one is thrown again here once every thread has left f: nothing unwinds
+// past the pool while its workers still hold references to this frame. A call made from inside f runs serially (the
+// pool's mutex is never tried by the thread that holds it).
 template <class F>
 static void parallel_for(size_t n, unsigned threads, F f) {
-    if (threads <= 1 || n <= 1) {
+    static thread_local bool inside = false;
+    if (threads <= 1 || n <= 1 || inside) {
         for (size_t i = 0; i < n; i++) f(i);
         return;
     }
     std::atomic<size_t> next{0};
+    std::exception_ptr first;
+    std::mutex first_mutex;
     const size_t tasks = std::min<size_t>(threads, n);
     auto body = [&](size_t) {
-        for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+        inside = true;
+        try {
+            for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(first_mutex);
+            if (!first) first = std::current_exception();
+            next.store(n);  // the other threads stop at their next index
+        }
+        inside = false;
     };
-    std::unique_lock<std::mutex> lk(host_pool_mutex, std::try_to_lock);
-    if (lk.owns_lock()) {
-        host_pool().run(tasks, body);
-        return;
+    {
+        std::unique_lock<std::mutex> lk(host_pool_mutex, std::try_to_lock);
+        if (lk.owns_lock()) {
+            host_pool().run(tasks, body);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < tasks; t++) pool.emplace_back([&] { body(t); });
+            for (auto& th : pool) th.join();
+        }
     }
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < tasks; t++) pool.emplace_back([&] { body(t); });
-    for (auto& th : pool) th.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // The same checks on the device: one lane per (proof, layer, sample) and per (proof, position).

@@ -185,3 +185,42 @@ def test_two_rank_gloo_batch_partitioning(tmp_path):
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ok" in r.stdout
+
+
+def test_default_device_follows_the_caller_before_local_rank(monkeypatch):
+    """Which GPU the default context opens: a caller that has already chosen a device through torch keeps it, even
+    device 0 under torchrun; only a process that has not touched torch.cuda falls back to its LOCAL_RANK."""
+    from stark_verifier_amd import _lib
+
+    class FakeCuda:
+        def __init__(self, initialised, current, count):
+            self._i, self._c, self._n = initialised, current, count
+
+        def is_available(self):
+            return True
+
+        def is_initialized(self):
+            return self._i
+
+        def current_device(self):
+            return self._c
+
+        def device_count(self):
+            return self._n
+
+    class FakeTorch:
+        def __init__(self, cuda):
+            self.cuda = cuda
+
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setattr(_lib, "torch", FakeTorch(FakeCuda(True, 0, 8)))
+    assert _lib.current_device() == 0      # the caller set device 0 on purpose
+    monkeypatch.setattr(_lib, "torch", FakeTorch(FakeCuda(True, 5, 8)))
+    assert _lib.current_device() == 5
+    monkeypatch.setattr(_lib, "torch", FakeTorch(FakeCuda(False, 0, 8)))
+    assert _lib.current_device() == 3      # nothing chosen yet: one process per GPU
+    monkeypatch.setattr(_lib, "torch", FakeTorch(FakeCuda(False, 0, 1)))
+    assert _lib.current_device() == 0      # per-rank HIP_VISIBLE_DEVICES: only one GPU to see
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.setattr(_lib, "torch", FakeTorch(FakeCuda(False, 0, 8)))
+    assert _lib.current_device() == 0

@@ -89,3 +89,39 @@ def test_static_scratch_entry_point_matches_the_allocating_one():
         assert _static(ctx, x, y, 20, 1, limbs, False) == _lib.STARK_ERR_INVALID
     finally:
         ctx.close()
+
+
+def test_static_entry_point_allocates_nothing_and_serves_two_contexts_in_turn():
+    """What the entry point is for: the device's free memory is the same after the calls as before them (a hipMalloc
+    of any size would take at least one allocation granule), also at the 2^20-point size, whose allocating twin takes
+    another kernel path; and two contexts on one GPU, which share the GPU's one scratch array, give the right bytes when
+    their calls come one after the other."""
+    import stark_verifier_amd as sv
+    from stark_verifier_amd import fft, _lib
+    a, b = sv.Context(0), sv.Context(0)
+    try:
+        cases = [(16, 24, False), (20, 9, True), (14, 3, False)]
+        prepared = []
+        for step, (log_n, batch, inverse) in enumerate(cases):
+            w, limbs = _root(log_n)
+            x = _fill(a, batch * (1 << log_n), 0xBEE + step)
+            ref = torch.empty_like(x)
+            fft.ntt_batch_dev(x.data_ptr(), ref.data_ptr(), log_n, batch, w, inverse, a)      # tables of context a
+            fft.ntt_batch_dev(x.data_ptr(), ref.data_ptr(), log_n, 0, w, inverse, b)          # tables of context b
+            a.synchronize()
+            b.synchronize()
+            prepared.append((log_n, batch, inverse, limbs, x, ref, torch.full_like(x, -1), torch.full_like(x, -1)))
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for log_n, batch, inverse, limbs, x, ref, ya, yb in prepared:
+            assert _static(a, x, ya, log_n, batch, limbs, inverse) == _lib.STARK_OK, a.lib.stark_last_error(a.handle)
+            a.synchronize()
+            assert _static(b, x, yb, log_n, batch, limbs, inverse) == _lib.STARK_OK, b.lib.stark_last_error(b.handle)
+            b.synchronize()
+        free_after = torch.cuda.mem_get_info()[0]
+        assert free_after == free_before, (free_before, free_after)
+        for log_n, batch, inverse, limbs, x, ref, ya, yb in prepared:
+            assert torch.equal(ya, ref) and torch.equal(yb, ref), (log_n, batch, inverse)
+    finally:
+        a.close()
+        b.close()
