@@ -715,11 +715,12 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
             a.outP = a.poly_stride;
             a.ksh = 31;
             a.kmask = 0xFFFFFFFFu;
-            // The streaming kernels pay from a few work items per resident workgroup on (below that nothing is left to
-            // fetch ahead, and zeroing the counters is a launch of its own); calls that override the last pass and the
-            // allocation-free entry point keep to the plain kernels.
+            // The streaming kernels pay from 16 work items per resident workgroup on (16 polynomials of 2^20 points on 256
+            // compute units; measured: -3 % at 4 polynomials, -1 % at 8, even at 16, +1.5 % at 32, +3.4 % at 64: with
+            // few items little is left to fetch ahead, and zeroing the counters is a launch of its own); calls that
+            // override the last pass and the allocation-free entry point keep to the plain kernels.
             if (plan->stream_tw && !ov && !fixed &&
-                (uint64_t)p.tiles * cnt >= (uint64_t)env_int("STARKHIP_STREAM_MIN", 4) * ntt29_stream_resident(ctx->n_cu)) {
+                (uint64_t)p.tiles * cnt >= (uint64_t)env_int("STARKHIP_STREAM_MIN", 16) * ntt29_stream_resident(ctx->n_cu)) {
                 uint32_t* tk = nullptr;
                 for (auto& t : ctx->tickets)
                     if (t.first == stream) tk = t.second;

@@ -20,22 +20,14 @@ N = 1 << LOG_N
 W = pow(7, (P - 1) >> LOG_N, P)
 
 
-def _ctx(stream_on, **env):
+def _ctx(monkeypatch, stream_on, **env):
+    """A fresh context whose plans are built with the streaming form on or off (the planner reads the switches when it
+    builds a plan; monkeypatch puts the environment back after the test)."""
     import stark_verifier_amd as sv
-    old = {k: os.environ.get(k) for k in ["STARKHIP_STREAM", *env]}
-    os.environ["STARKHIP_STREAM"] = "1" if stream_on else "0"
+    monkeypatch.setenv("STARKHIP_STREAM", "1" if stream_on else "0")
     for k, v in env.items():
-        os.environ[k] = str(v)
-    ctx = sv.Context(0)
-    return ctx, old
-
-
-def _restore(old):
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+        monkeypatch.setenv(k, str(v))
+    return sv.Context(0)
 
 
 def _fill(ctx, count, seed):
@@ -60,15 +52,17 @@ def _run(ctx, x, batch, inverse, in_place=False, stream=None):
 
 
 @pytest.mark.parametrize("batch", [1, 7, 8, 11, 24])
-def test_streaming_and_plain_kernels_give_the_same_bytes(batch):
-    # batch 1 and 7 stay below the streaming threshold (plain kernels in both contexts), 8 is the first size above it
-    plain, old = _ctx(False)
+def test_streaming_and_plain_kernels_give_the_same_bytes(batch, monkeypatch):
+    # with the threshold lowered to 4 items per resident workgroup, batch 1 and 7 stay below it (plain kernels in both
+    # contexts) and 8 is the first size above it; the default threshold (16) is met by the 64 polynomials of
+    # tests/test_gpu_full_size.py
+    plain = _ctx(monkeypatch, False)
+    x = _fill(plain, batch * N, 100 + batch)
+    ref_f = _run(plain, x, batch, False)
+    ref_i = _run(plain, x, batch, True)
+    plain.close()
+    fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=4)
     try:
-        x = _fill(plain, batch * N, 100 + batch)
-        ref_f = _run(plain, x, batch, False)
-        ref_i = _run(plain, x, batch, True)
-        plain.close()
-        fast, _ = _ctx(True)
         for _ in range(2):  # twice: the work counters of the first run must not leak into the second
             assert torch.equal(_run(fast, x, batch, False), ref_f)
             assert torch.equal(_run(fast, x, batch, True), ref_i)
@@ -78,9 +72,8 @@ def test_streaming_and_plain_kernels_give_the_same_bytes(batch):
         s = torch.cuda.Stream()
         torch.cuda.synchronize()
         assert torch.equal(_run(fast, x, batch, False, stream=s), ref_f)
-        fast.close()
     finally:
-        _restore(old)
+        fast.close()
     # the oracle on the first and the last polynomial
     for b in (0, batch - 1):
         xin = x[b * N:(b + 1) * N].cpu().numpy().view(np.uint32)
@@ -88,30 +81,26 @@ def test_streaming_and_plain_kernels_give_the_same_bytes(batch):
     assert np.array_equal(ref_i[:N].cpu().numpy().view(np.uint32), oracle.fft_inv(x[:N].cpu().numpy().view(np.uint32), W))
 
 
-def test_streaming_with_every_item_count_per_workgroup():
+def test_streaming_with_every_item_count_per_workgroup(monkeypatch):
     # threshold 1: also the sizes where a resident workgroup gets one or two items and the counters run out at once
     for batch in (1, 2, 3):
-        plain, old = _ctx(False)
-        try:
-            x = _fill(plain, batch * N, 7 + batch)
-            ref = _run(plain, x, batch, False)
-            plain.close()
-            fast, _ = _ctx(True, STARKHIP_STREAM_MIN=1)
-            assert torch.equal(_run(fast, x, batch, False), ref), batch
-            fast.close()
-        finally:
-            _restore(old)
-
-
-def test_streaming_with_fewer_resident_workgroups_than_the_chip_holds():
-    # one workgroup per compute unit: every workgroup walks twice as many items
-    plain, old = _ctx(False)
-    try:
-        x = _fill(plain, 8 * N, 99)
-        ref = _run(plain, x, 8, True)
+        plain = _ctx(monkeypatch, False)
+        x = _fill(plain, batch * N, 7 + batch)
+        ref = _run(plain, x, batch, False)
         plain.close()
-    finally:
-        _restore(old)
+        fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=1)
+        try:
+            assert torch.equal(_run(fast, x, batch, False), ref), batch
+        finally:
+            fast.close()
+
+
+def test_streaming_with_fewer_resident_workgroups_than_the_chip_holds(monkeypatch):
+    # one workgroup per compute unit: every workgroup walks twice as many items
+    plain = _ctx(monkeypatch, False)
+    x = _fill(plain, 8 * N, 99)
+    ref = _run(plain, x, 8, True)  # (8 polynomials = 16 items for each of the 256 workgroups the child keeps resident)
+    plain.close()
     import subprocess, sys
     # STARKHIP_STREAM_WGS is read once per process, so this case runs in a child
     code = (
