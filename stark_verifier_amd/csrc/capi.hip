@@ -47,7 +47,7 @@ struct NttPlan {
     uint64_t cols = 0;        // column plans: columns of the matrix; stage A tables: world << 32 | rank
     size_t table_bytes = 0;   // device memory held by `tables`
     uint64_t last_use = 0;    // for least-recently-used eviction
-    // two passes of 1024-point tiles: the streaming kernels (ntt29.hip) take them unless a call overrides the last pass;
+    // two passes of 1024-point or of 256-point tiles: the streaming kernels (ntt29.hip) take them unless a call overrides the last pass;
     // the last pass then applies the inter-pass factors, row k1 of the table holding w^(k1 * j) for its m inputs
     const uint32_t* stream_tw = nullptr;
     uint64_t stream_m = 0;
@@ -518,7 +518,8 @@ int build_plan(stark_ctx* ctx, unsigned log_n, const U256& root, bool inverse, N
             set_quarter_root(a, w2, l2);
             p.tiles = (unsigned)(n1 >> a.log_c);
             plan->passes.push_back(p);
-            if (tiled_mid && l1 == 10 && l2 == 10 && plan->passes[0].args.log_c == 1 && a.log_c == 1 &&
+            if (tiled_mid && l1 == l2 && (l1 == 10 || l1 == 8) && plan->passes[0].args.log_c == (uint32_t)(11 - l1) &&
+                a.log_c == (uint32_t)(11 - l1) && p.tiles % 8 == 0 && plan->passes[0].tiles % 8 == 0 &&
                 env_int("STARKHIP_STREAM", 1) != 0) {
                 plan->stream_tw = TW1;
                 plan->stream_m = m;

@@ -166,7 +166,7 @@ __device__ unsigned long long g_stamps[2][8192][8][24];
 //   6 single pass, no output factor: packed on both sides, element index fastest, no table
 // Kinds 1, 2, 4, 5 (the passes of multi-pass plans) also know that every tile of the grid exists and how many tiles a
 // workgroup takes; all but 0 know that the output index is not split.
-//   7, 8 "streaming" first and last pass of two at 1024-point tiles: a fixed grid of resident workgroups, each walking
+//   7, 8 "streaming" first and last pass of two at 1024- or 256-point tiles: a fixed grid of resident workgroups, each walking
 //     through work items blockIdx.x, blockIdx.x + gridDim.x, ...; the next item's input is fetched straight into LDS
 //     (global_load_lds, no registers) while the last round of the current item computes and stores, so that no
 //     wavefront waits for global memory at the start of an item (see "landing" below). That costs a workgroup barrier
@@ -183,7 +183,7 @@ typedef __attribute__((address_space(1))) const void* lds_dma_src_t;
 template <int LOGT, int KIND>
 __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     constexpr bool STREAM = KIND == KIND_SFIRST || KIND == KIND_SLAST;
-    static_assert(!STREAM || LOGT == 10, "the landing layout of the streaming kinds is laid out for two 1024-point tiles per workgroup");
+    static_assert(!STREAM || LOGT == 10 || LOGT == 8, "the landing layouts of the streaming kinds are laid out for 1024- and 256-point tiles");
     constexpr bool MULTI = KIND == KIND_FIRST || KIND == KIND_LAST || KIND == KIND_MID || KIND == KIND_LAST3 || STREAM;
     constexpr bool ONE = KIND == KIND_FOLD || KIND == KIND_SINGLE;
     constexpr bool SPECIAL = MULTI || ONE;
@@ -324,25 +324,32 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
     // ---- landing (streaming kinds) ----------------------------------------------------------------------------
     // A global_load_lds instruction deposits 4 or 16 bytes per lane at consecutive addresses from a wave-uniform LDS
     // base (lane L at base + 4 L or 16 L), each lane naming its own global address, which need only be 4-byte aligned
-    // (measured, tools/probe/lds_dma_probe.hip). Both kinds run round 0 tile index fastest, lane (c, j) = (tid & 1,
-    // tid >> 1).
-    //   kind 7 (packed 32-byte elements, two adjacent columns). Every wavefront fetches exactly what it reads itself in
+    // (measured, tools/probe/lds_dma_probe.hip). Both kinds run round 0 tile index fastest, lane (c, j) = (tid mod C,
+    // tid / C) with C = 2 tiles of 1024 points or 8 tiles of 256 points per workgroup; a wavefront covers J = 64 / C
+    // consecutive j and all C tiles.
+    //   kind 7 (packed 32-byte elements, C adjacent columns). Every wavefront fetches exactly what it reads itself in
     //     round 0, into the part of the image that only it writes in round 0; nothing else touches that part between the
     //     barrier after the last round's LDS reads and the barrier after round 0, so the fetch needs no barrier of its
-    //     own. Lane (c, j) writes positions 4j .. 4j + 3 of tile c, i.e. slot swz(j) of sub-images 0..3, so wavefront
-    //     w (j in [32w, 32w + 32)) owns eight chunks of 32 slots = 1152 bytes at slot 32w of sub-image k of tile c, chunk
-    //     i = 4c + k. One instruction per chunk: chunk i takes rows 32w + 256 (i >> 1) + 16 (i & 1) + (0..15), four lanes
-    //     per 64-byte run; lane (c, jj = j mod 32) finds input q in chunk 2q + (jj >> 4) at byte 32 ((jj & 15) * 2 + c).
-    //   kind 8 (36-byte elements of the tiled intermediate: runs of four elements = 144 bytes = nine 16-byte pieces
-    //     holding rows c = 0, 1 at j even, odd). A wavefront's 576 pieces do not fit its own chunks in whole
-    //     instructions, so the workgroup's 512 runs land back to back from LDS byte 0 (run t = j >> 1 at 144 t, nine
-    //     instructions per wavefront) and round 0 reads element (c, j) at 144 (j >> 1) + 36 (2c + (j & 1)), between two
-    //     barriers: every wavefront's pieces have landed / every lane has read, before round 0 overwrites the image.
-    //     (Measured against a variant that keeps kind 8 free of those barriers by running round 0 element index
-    //     fastest, each wavefront fetching its own 36-byte elements as 16 + 16 + 4 bytes: 3 % slower, the fetch then
-    //     takes its runs apart.)
+    //     own. Lane (c, j) writes positions 4j .. 4j + 3 of tile c: at 1024 points slot swz(j) of sub-images 0..3, so
+    //     wavefront w owns the 32 slots from 32w of sub-image k of tile c (chunk i = 4c + k); at 256 points, where a tile
+    //     is one sub-image, the 32 slots from 32w of tile c (chunk i = c): eight chunks of 1152 bytes either way. One
+    //     instruction per chunk: instruction i = 2q + h takes rows Jw + (T/4) q + (J/2) h + (0 .. J/2 - 1) of all C
+    //     columns, 2C lanes per run of 32 C bytes; lane (c, jj = j mod J) finds input q in chunk 2q + jj / (J/2) at byte
+    //     32 ((jj mod (J/2)) * C + c).
+    //   kind 8 (36-byte elements of the tiled intermediate: runs of C * C elements holding rows c = 0 .. C-1 at C
+    //     consecutive j, 144 or 2304 bytes). A wavefront's 576 pieces of 16 bytes do not fit its own chunks in whole
+    //     instructions, so the workgroup's runs land back to back from LDS byte 0 (nine instructions per wavefront) and
+    //     round 0 reads element (c, j) at dword 9 ((j / C) * C * C + c * C + j mod C), between two barriers: every
+    //     wavefront's pieces have landed / every lane has read, before round 0 overwrites the image. (Measured at 1024
+    //     points against a variant that keeps kind 8 free of those barriers by running round 0 element index fastest,
+    //     each wavefront fetching its own 36-byte elements as 16 + 16 + 4 bytes: 3 % slower, the fetch then takes its
+    //     runs apart.)
+    constexpr uint32_t SLC = LOGT <= 11 ? 11 - LOGT : 0, SC = 1u << SLC, SJ = 64u >> SLC;  // log2 C, C, J of the streaming kinds
     uint32_t wv = STREAM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) : 0u, ln = tid & 63u;
-    auto chunk = [&](uint32_t i) -> uint32_t { return ((i >> 2) * Tp + (i & 3u) * G::SB + 32u * wv) * 9u; };  // dword index
+    auto chunk = [&](uint32_t i) -> uint32_t {  // dword index of chunk i of this wavefront
+        if (LOGT == 10) return ((i >> 2) * Tp + (i & 3u) * G::SB + 32u * wv) * 9u;
+        return (i * Tp + 32u * wv) * 9u;
+    };
     auto issue_landing = [&](uint32_t it) {
         uint32_t tau2, pidx2;
         decode(it, tau2, pidx2);
@@ -350,39 +357,42 @@ __global__ void __launch_bounds__(1024) ntt29_pass_kernel(const NttPassArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (KIND == KIND_SFIRST) {
             const uint64_t rs = a.inS * 32;  // bytes between rows
-            const char* g = reinterpret_cast<const char*>(a.in) + 32 * base + (uint64_t)(32u * wv + (ln >> 2)) * rs + (ln & 3u) * 16u;
+            const char* g = reinterpret_cast<const char*>(a.in) + 32 * base + (uint64_t)(SJ * wv + (ln >> (SLC + 1))) * rs +
+                            (ln & (2u * SC - 1u)) * 16u;
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++)
-                __builtin_amdgcn_global_load_lds((lds_dma_src_t)(g + (uint64_t)(256u * (i >> 1) + 16u * (i & 1u)) * rs),
+                __builtin_amdgcn_global_load_lds((lds_dma_src_t)(g + (uint64_t)(Q * (i >> 1) + (SJ / 2) * (i & 1u)) * rs),
                                                  (lds_dma_dst_t)(lds + chunk(i)), 16, 0, 0);
         } else if (KIND == KIND_SLAST) {
+            constexpr uint32_t PPR = 9u * SC * SC / 4u;  // 16-byte pieces per run
             const uint32_t rs = (uint32_t)a.inS2 * 36u;  // bytes between runs (the last run starts below 2^32)
             const char* g = reinterpret_cast<const char*>(a.in) + 36 * base;
 #pragma unroll
             for (uint32_t i = 0; i < 9; i++) {
-                const uint32_t piece = (wv * 9u + i) * 64u + ln, t = (piece * 7282u) >> 16, part = piece - 9u * t;  // t = piece / 9
+                const uint32_t piece = (wv * 9u + i) * 64u + ln, t = piece / PPR, part = piece - PPR * t;
                 __builtin_amdgcn_global_load_lds((lds_dma_src_t)(g + ((uint64_t)t * rs + part * 16u)),
                                                  (lds_dma_dst_t)(lds + (wv * 9u + i) * 256u), 16, 0, 0);
             }
         }
 #endif
     };
-    // the lane's four inputs from the landing (round 0 of a streaming kind), lane (c, j) = (tid & 1, tid >> 1)
+    // the lane's four inputs from the landing (round 0 of a streaming kind), lane (c, j) = (tid mod C, tid / C)
     auto landed_inputs = [&]() -> Quad29 {
         F29 x[4];
+        const uint32_t cc = ln & (SC - 1u);
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
             if (KIND == KIND_SFIRST) {
-                const uint32_t jj = ln >> 1, cc = ln & 1u;
-                const uint4* p4 = reinterpret_cast<const uint4*>(lds + chunk(2 * q + (jj >> 4)) + 8u * (((jj & 15u) << 1) + cc));
+                const uint32_t jj = ln >> SLC;  // j mod J
+                const uint4* p4 = reinterpret_cast<const uint4*>(lds + chunk(2 * q + jj / (SJ / 2)) + 8u * ((jj % (SJ / 2)) * SC + cc));
                 const uint4 u0 = p4[0], u1 = p4[1];
                 Fe f;
                 f.l[0] = u0.x; f.l[1] = u0.y; f.l[2] = u0.z; f.l[3] = u0.w;
                 f.l[4] = u1.x; f.l[5] = u1.y; f.l[6] = u1.z; f.l[7] = u1.w;
                 x[q] = f29_from_fe(f);
             } else {
-                const uint32_t jq = (tid >> 1) + q * Q;
-                const uint32_t* p1 = lds + 36u * (jq >> 1) + 9u * (2u * (ln & 1u) + (jq & 1u));
+                const uint32_t jq = (tid >> SLC) + q * Q;
+                const uint32_t* p1 = lds + 9u * (((jq >> SLC) << (2 * SLC)) + (cc << SLC) + (jq & (SC - 1u)));
 #pragma unroll
                 for (int l = 0; l < 9; l++) x[q].l[l] = p1[l];
             }
@@ -757,8 +767,8 @@ static hipError_t launch_either29(const NttPassArgs& a, unsigned tiles, unsigned
         // slower than the general kernel at 2^12 points, 128 registers against 123)
     }
     if (a.stream) {  // the planner sets this only for the shapes the streaming kinds are written for
-        constexpr bool S = LOGT == 10;
-        if (!S || a.log_c != 1 || !a.load_cfast || !a.store_cfast || a.ksh != 31 || a.c_limit != ~0ull || a.has_scale || tiles % 8u)
+        constexpr bool S = LOGT == 10 || LOGT == 8;
+        if (!S || a.log_c != (uint32_t)(11 - LOGT) || !a.load_cfast || !a.store_cfast || a.ksh != 31 || a.c_limit != ~0ull || a.has_scale || tiles % 8u)
             return hipErrorInvalidConfiguration;
         if (!a.in_raw) return launch_one29<LOGT, (S ? KIND_SFIRST : KIND_GENERAL)>(g, tiles, polys, stream);
         return launch_one29<LOGT, (S ? KIND_SLAST : KIND_GENERAL)>(g, tiles, polys, stream);

@@ -1,4 +1,4 @@
-"""The streaming form of the two-pass transform at 2^20 points (resident workgroups that fetch the next work item
+"""The streaming form of the two-pass transforms at 2^20 and 2^16 points (resident workgroups that fetch the next work item
 straight into LDS while the current one finishes, work handed out by per-XCD counters) against the plain kernels and
 the oracle: same bytes for every batch size, both directions, in and out of place, on the context's own stream and on
 a stream of the caller's, and twice in a row in one context (the counters are zeroed per launch).
@@ -15,9 +15,10 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 P = oracle.P
-LOG_N = 20
-N = 1 << LOG_N
-W = pow(7, (P - 1) >> LOG_N, P)
+
+
+def _root(log_n):
+    return pow(7, (P - 1) >> log_n, P)
 
 
 def _ctx(monkeypatch, stream_on, **env):
@@ -37,8 +38,9 @@ def _fill(ctx, count, seed):
     return t
 
 
-def _run(ctx, x, batch, inverse, in_place=False, stream=None):
+def _run(ctx, x, batch, inverse, in_place=False, stream=None, log_n=20):
     from stark_verifier_amd import fft
+    LOG_N, W = log_n, _root(log_n)
     y = x.clone() if in_place else torch.empty_like(x)
     torch.cuda.synchronize()  # the copy runs on torch's stream, the transform on the library's
     src = y if in_place else x
@@ -51,27 +53,28 @@ def _run(ctx, x, batch, inverse, in_place=False, stream=None):
     return y
 
 
-@pytest.mark.parametrize("batch", [1, 7, 8, 11, 24])
-def test_streaming_and_plain_kernels_give_the_same_bytes(batch, monkeypatch):
-    # with the threshold lowered to 4 items per resident workgroup, batch 1 and 7 stay below it (plain kernels in both
-    # contexts) and 8 is the first size above it; the default threshold (16) is met by the 64 polynomials of
-    # tests/test_gpu_full_size.py
+@pytest.mark.parametrize("log_n,batch", [(20, 1), (20, 7), (20, 8), (20, 11), (20, 24), (16, 100), (16, 128), (16, 333), (16, 1024)])
+def test_streaming_and_plain_kernels_give_the_same_bytes(log_n, batch, monkeypatch):
+    # with the threshold lowered to 4 items per resident workgroup, 1 and 7 polynomials of 2^20 points (100 of 2^16) stay
+    # below it (plain kernels in both contexts) and 8 (128) is the first size above it; the default threshold (16) is met
+    # by the 64 polynomials of 2^20 and the 1024 of 2^16 points of tests/test_gpu_full_size.py
+    N, W = 1 << log_n, _root(log_n)
     plain = _ctx(monkeypatch, False)
     x = _fill(plain, batch * N, 100 + batch)
-    ref_f = _run(plain, x, batch, False)
-    ref_i = _run(plain, x, batch, True)
+    ref_f = _run(plain, x, batch, False, log_n=log_n)
+    ref_i = _run(plain, x, batch, True, log_n=log_n)
     plain.close()
     fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=4)
     try:
         for _ in range(2):  # twice: the work counters of the first run must not leak into the second
-            assert torch.equal(_run(fast, x, batch, False), ref_f)
-            assert torch.equal(_run(fast, x, batch, True), ref_i)
-        assert torch.equal(_run(fast, x, batch, False, in_place=True), ref_f)
-        assert torch.equal(_run(fast, x, batch, True, in_place=True), ref_i)
+            assert torch.equal(_run(fast, x, batch, False, log_n=log_n), ref_f)
+            assert torch.equal(_run(fast, x, batch, True, log_n=log_n), ref_i)
+        assert torch.equal(_run(fast, x, batch, False, in_place=True, log_n=log_n), ref_f)
+        assert torch.equal(_run(fast, x, batch, True, in_place=True, log_n=log_n), ref_i)
         # a stream of the caller's (its own counters)
         s = torch.cuda.Stream()
         torch.cuda.synchronize()
-        assert torch.equal(_run(fast, x, batch, False, stream=s), ref_f)
+        assert torch.equal(_run(fast, x, batch, False, stream=s, log_n=log_n), ref_f)
     finally:
         fast.close()
     # the oracle on the first and the last polynomial
@@ -83,14 +86,15 @@ def test_streaming_and_plain_kernels_give_the_same_bytes(batch, monkeypatch):
 
 def test_streaming_with_every_item_count_per_workgroup(monkeypatch):
     # threshold 1: also the sizes where a resident workgroup gets one or two items and the counters run out at once
-    for batch in (1, 2, 3):
+    # (512 work items per polynomial of 2^20 points, 32 per polynomial of 2^16)
+    for log_n, batch in ((20, 1), (20, 2), (20, 3), (16, 16), (16, 17), (16, 40)):
         plain = _ctx(monkeypatch, False)
-        x = _fill(plain, batch * N, 7 + batch)
-        ref = _run(plain, x, batch, False)
+        x = _fill(plain, batch << log_n, 7 + batch)
+        ref = _run(plain, x, batch, False, log_n=log_n)
         plain.close()
         fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=1)
         try:
-            assert torch.equal(_run(fast, x, batch, False), ref), batch
+            assert torch.equal(_run(fast, x, batch, False, log_n=log_n), ref), (log_n, batch)
         finally:
             fast.close()
 
@@ -98,6 +102,7 @@ def test_streaming_with_every_item_count_per_workgroup(monkeypatch):
 def test_streaming_with_fewer_resident_workgroups_than_the_chip_holds(monkeypatch):
     # one workgroup per compute unit: every workgroup walks twice as many items
     plain = _ctx(monkeypatch, False)
+    N, W = 1 << 20, _root(20)
     x = _fill(plain, 8 * N, 99)
     ref = _run(plain, x, 8, True)  # (8 polynomials = 16 items for each of the 256 workgroups the child keeps resident)
     plain.close()
