@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 timeout -k 10 400 python3 bench.py --steps 5 --warmup 2 > gpurun_out/rehearse_n1.json 2> gpurun_out/rehearse_n1.err || { echo "n1 failed"; exit 1; }
 echo "n1 ok"
 export STARKHIP_BENCH_BACKEND=gloo
-SMALL="--gpus 2 --steps 2 --warmup 1 --ntt-batch 8 --merkle-n 65536 --merkle-total 65536 --proofs 50 --proofs-total 100 --sharded-log-n 22"
+SMALL="--gpus 2 --steps 2 --warmup 1 --ntt-batch 32 --merkle-n 65536 --merkle-total 65536 --proofs 50 --proofs-total 100 --sharded-log-n 22"
 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py $SMALL > gpurun_out/rehearse_n2.json 2> gpurun_out/rehearse_n2.err || { echo "n2 failed"; exit 1; }
 echo "n2 ok"
 STARKHIP_BENCH_FAIL=sharded_ntt:1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py $SMALL --region-timeout 0.2 > gpurun_out/rehearse_n2_fail1.json 2> gpurun_out/rehearse_n2_fail1.err && { echo "n2 fail1: status 0 although a region failed"; exit 1; }
