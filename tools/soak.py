@@ -1,5 +1,8 @@
 """Randomized soak: transforms and Merkle batches of random shapes against the CPU oracle for a given number of
-seconds. python tools/soak.py [seconds] [seed]. Test infrastructure (uses the oracle); prints a summary line."""
+seconds. python tools/soak.py [seconds] [seed]. Test infrastructure (uses the oracle); prints a summary line.
+One case in ten is a batch of 2^16- or 2^20-point polynomials through the device-resident entry point with the
+streaming kernels' batch threshold lowered to one work item per workgroup, so that their landing, ticket and tail paths
+see every item count."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -8,16 +11,38 @@ import oracle, synth
 import stark_verifier_amd as sv
 
 P = oracle.P
+os.environ.setdefault("STARKHIP_STREAM_MIN", "1")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-n_ntt = n_mk = 0
+n_ntt = n_mk = n_stream = 0
 t_say = time.time() + 30
 while time.time() < t_end:
     if time.time() > t_say:   # a line every half minute: a silent run is taken to be hung
         print("... %d s left" % int(t_end - time.time()), flush=True)
         t_say = time.time() + 30
-    if rng.random() < 0.6:
+    r_case = rng.random()
+    if r_case < 0.1:
+        import torch
+        log_n = int(rng.choice([16, 16, 20]))
+        n = 1 << log_n
+        batch = int(rng.integers(1, 7)) if log_n == 20 else int(rng.integers(1, 97))
+        w = pow(7, (P - 1) >> log_n, P)
+        ctx = sv.default_context()
+        x = torch.empty((batch * n, 8), dtype=torch.int32, device="cuda")
+        ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, x.data_ptr(), batch * n, int(rng.integers(1 << 30)), None))
+        inverse = bool(rng.integers(2))
+        in_place = bool(rng.integers(2))
+        y = x.clone() if in_place else torch.empty_like(x)
+        torch.cuda.synchronize()
+        sv.fft.ntt_batch_dev((y if in_place else x).data_ptr(), y.data_ptr(), log_n, batch, w, inverse, ctx)
+        ctx.synchronize()
+        for b in {0, batch - 1}:
+            xin = x[b * n:(b + 1) * n].cpu().numpy().view(np.uint32)
+            exp = oracle.fft_inv(xin, w) if inverse else oracle.fft_fwd(xin, w)
+            assert np.array_equal(y[b * n:(b + 1) * n].cpu().numpy().view(np.uint32), exp), ("stream", log_n, batch, inverse, in_place, b)
+        n_stream += 1
+    elif r_case < 0.64:
         log_n = int(rng.integers(0, 17))
         n = 1 << log_n
         batch = int(rng.integers(1, max(2, min(300, (1 << 18) // n))))
@@ -51,4 +76,4 @@ while time.time() < t_end:
         exp = oracle.merkle_verify_batch(vals, case["siblings"], wit, idx, case["root"])
         assert np.array_equal(acc, exp), ("merkle", w, vs, n)
         n_mk += 1
-print("soak ok: %d transform cases, %d merkle cases in %.0f s" % (n_ntt, n_mk, budget))
+print("soak ok: %d transform cases, %d streaming-kernel batches, %d merkle cases in %.0f s" % (n_ntt, n_stream, n_mk, budget))
