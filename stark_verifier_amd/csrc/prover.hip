@@ -149,6 +149,70 @@ __global__ void __launch_bounds__(256) columns_kernel(Dev D) {
     store_be(leaf + 64, b);
 }
 
+// ---- D, B, the 96-byte leaves and the first level of the trace tree in one go: lane = (proof, pair of leaves) ----
+// Leaves 2j and 2j + 1 of the tree order are points r + q N/4 and r + (q + 1) N/4 with r = j >> 1, q = 2 (j & 1)
+// (perm4 above, inverted). The lane computes both points' (P, D, B), stores the two leaves (192 contiguous bytes) and
+// hashes them from registers: the 192-byte message is six 32-byte big-endian values, word w of a value being the
+// byte-swapped limb 7 - w, so the three message blocks are (P0, D0), (B0, P1), (D1, B1) and each is compressed as soon as
+// its second value exists. Against columns_kernel + leaf_pairs_kernel this saves reading the leaves back (6 of the
+// 14 MiB the two kernels move per proof) and one launch; STARKHIP_PROVER_FUSE=0 keeps the two kernels.
+__device__ __forceinline__ void be_words(uint32_t* m, const Fe& x) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) m[w] = __builtin_bswap32(x.l[7 - w]);
+}
+
+__global__ void __launch_bounds__(256) columns_pairs_kernel(Dev D) {
+    const uint32_t pr = blockIdx.y, N = 1u << D.log_n, half = N >> 1, quarter = N >> 2;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    const uint32_t* Pp = D.P + 8 * ((size_t)pr << D.log_n);
+    const F29 inp = load_limbs(D.io + 16 * (size_t)pr), slope = load_limbs(D.io + 16 * (size_t)pr + 8);
+    uint4* leaf = reinterpret_cast<uint4*>(D.leaves + 96 * (((size_t)pr << D.log_n) + 2 * (size_t)j));
+    uint32_t h[8], m[16];
+    b2s_init(h);
+    Fe b0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const uint32_t i = (j >> 1) + (2u * (j & 1u) + (uint32_t)s) * quarter;
+        const F29 p = load_limbs(Pp + 8 * (size_t)i), pg = load_limbs(Pp + 8 * (size_t)((i + EXT) & (N - 1)));
+        const F29 k = load_limbs(D.kext + 8 * (size_t)(i & D.ext_mask));
+        const F29 x = load_limbs(D.xs + 8 * (size_t)i);
+        const F29 p3 = mul_t(mul_t(p, p), p);
+        const F29 d = mul_t(f29_sub(f29_sub(pg, p3), k), load_limbs(D.zfac + 8 * (size_t)i));
+        const F29 interp = f29_add(inp, mul_t(f29_sub(x, one()), slope));
+        const F29 b = mul_t(f29_sub2(p, interp), load_limbs(D.invz2 + 8 * (size_t)i));
+        const Fe pe = f29_to_fe(p), de = f29_to_fe(d), be = f29_to_fe(b);
+        if (s == 0) {
+            be_words(m, pe);
+            be_words(m + 8, de);
+            leaf[0] = make_uint4(m[0], m[1], m[2], m[3]);
+            leaf[1] = make_uint4(m[4], m[5], m[6], m[7]);
+            leaf[2] = make_uint4(m[8], m[9], m[10], m[11]);
+            leaf[3] = make_uint4(m[12], m[13], m[14], m[15]);
+            b2s_compress(h, m, 64u, false);
+            b0 = be;
+        } else {
+            be_words(m, b0);
+            be_words(m + 8, pe);
+            leaf[4] = make_uint4(m[0], m[1], m[2], m[3]);
+            leaf[5] = make_uint4(m[4], m[5], m[6], m[7]);
+            leaf[6] = make_uint4(m[8], m[9], m[10], m[11]);
+            leaf[7] = make_uint4(m[12], m[13], m[14], m[15]);
+            b2s_compress(h, m, 128u, false);
+            be_words(m, de);
+            be_words(m + 8, be);
+            leaf[8] = make_uint4(m[0], m[1], m[2], m[3]);
+            leaf[9] = make_uint4(m[4], m[5], m[6], m[7]);
+            leaf[10] = make_uint4(m[8], m[9], m[10], m[11]);
+            leaf[11] = make_uint4(m[12], m[13], m[14], m[15]);
+            b2s_compress(h, m, 192u, true);
+        }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(D.tnodes + 32 * (((size_t)pr << D.log_n) + half + j));
+    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    dst[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
 // ---- first level of the trace tree: BLAKE2s over two 96-byte leaves; lane = (proof, pair) ----
 __global__ void __launch_bounds__(256) leaf_pairs_kernel(Dev D) {
     const uint32_t pr = blockIdx.y, half = 1u << (D.log_n - 1);
@@ -704,8 +768,13 @@ static int prove_chunk(stark_ctx* ctx, Plan& pl, uint32_t* d_trace, uint32_t* d_
     rc = stark_ntt_batch_dev(ctx, D.P, D.P, L.log_n, B, pl.g2l, 0, st);
     if (rc != STARK_OK) return rc;
     const dim3 gN((N + 255) / 256, B), gH((N / 2 + 255) / 256, B);
-    hipLaunchKernelGGL(columns_kernel, gN, dim3(256), 0, st, D);
-    hipLaunchKernelGGL(leaf_pairs_kernel, gH, dim3(256), 0, st, D);
+    static const bool fuse = !(getenv("STARKHIP_PROVER_FUSE") && atoi(getenv("STARKHIP_PROVER_FUSE")) == 0);
+    if (fuse) {
+        hipLaunchKernelGGL(columns_pairs_kernel, gH, dim3(256), 0, st, D);
+    } else {
+        hipLaunchKernelGGL(columns_kernel, gN, dim3(256), 0, st, D);
+        hipLaunchKernelGGL(leaf_pairs_kernel, gH, dim3(256), 0, st, D);
+    }
     P_TRY(hipGetLastError());
     if ((rc = build_trees_level(ctx, D.tnodes, (size_t)N * 32, N / 2, B, D.troot, st)) != STARK_OK) return rc;
     hipLaunchKernelGGL(coef_kernel, dim3((8 * B + 63) / 64), dim3(64), 0, st, D);
