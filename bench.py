@@ -159,6 +159,24 @@ class RegionGuard:
             self._leave(region, why)
 
 
+SETTLE_MS = 60.0
+
+
+def settle(fn, ms: float = SETTLE_MS):
+    """Keeps the chip busy with `fn` for `ms` milliseconds before a region is measured. After idle time (host-side
+    set-up, a parity check) the clocks need some tens of milliseconds of load to come back up: the first launches run
+    10-25 % slower, and a region whose warm-up and timed steps together last less than that (13 launches of the Merkle
+    kernel are 8 ms) would be measured on the ramp. Part of the set-up, like building a plan; the W warm-up steps and
+    the K timed steps follow unchanged."""
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= ms:
+            break
+
+
 def timed_region(fn, steps: int, warmup: int, world: int, coll_device):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
     Returns (seconds, max over ranks) and the mean per-step device time from events."""
@@ -317,11 +335,7 @@ def main():
     torch.cuda.synchronize()
     roundtrip_ok = bool(torch.equal(x, z))
     del z
-    # the chip's clocks take some tens of milliseconds of load to settle (the first launches after idle run 10-25 %
-    # slower): part of the set-up, like the plan, so that a short --warmup does not measure the ramp
-    for _ in range(8):
-        ntt_step()
-    torch.cuda.synchronize()
+    settle(ntt_step)
     dt_ntt, dev_ms_ntt = timed_region(ntt_step, args.steps, args.warmup, world, coll_device)
 
     # ---- region A2: the inverse transform (fft_inv semantics) on the same shape ----
@@ -377,9 +391,7 @@ def main():
     merkle_step()
     torch.cuda.synchronize()
     accept_ok = bool(np.array_equal(acc.cpu().numpy(), expect))
-    for _ in range(8):
-        merkle_step()
-    torch.cuda.synchronize()
+    settle(merkle_step)
     dt_mk, dev_ms_mk = timed_region(merkle_step, args.steps, args.warmup, world, coll_device)
 
     # ---- region B2 (BASELINE config 4): --merkle-total branches in total split over the ranks, verdicts gathered ----
@@ -417,6 +429,12 @@ def main():
         step_t()
         torch.cuda.synchronize()
         strong_ok = check_t()
+        if world == 1:
+            settle(step_t)
+        else:  # the step gathers over the ranks: every rank must run it the same number of times
+            for _ in range(16):
+                step_t()
+            torch.cuda.synchronize()
         dt_t, _ = timed_region(step_t, args.steps, args.warmup, world, coll_device)
         slices = {}
         if world == 1:
@@ -429,6 +447,7 @@ def main():
                 step_p()
                 torch.cuda.synchronize()
                 strong_ok = strong_ok and check_p()
+                settle(step_p)
                 dt_p, dev_p = timed_region(step_p, args.steps, args.warmup, 1, coll_device)
                 slices[str(parts)] = {"branches_per_rank": m, "ms_per_step": dt_p / args.steps * 1e3,
                                       "branches_per_s_one_rank": m * args.steps / dt_p}
@@ -461,6 +480,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": args.warmup,
+            "clock_settle_ms": SETTLE_MS,
             "ms_per_step": dt_ntt / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

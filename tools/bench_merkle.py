@@ -20,15 +20,17 @@ torch.cuda.synchronize()
 def step():
     ctx.check(ctx.lib.stark_merkle_verify_batch_dev(ctx.handle, vals.data_ptr(), sibs.data_ptr(), vs, wit.data_ptr(), w, idx.data_ptr(),
                                                     root.data_ptr(), None, n, acc.data_ptr(), None, None))
-for _ in range(3): step()
+WARM = int(os.environ.get("BENCH_WARMUP", "3"))
+STEPS = int(os.environ.get("BENCH_STEPS", "10"))
+for _ in range(WARM): step()
 ctx.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with torch.cuda.stream(ts):
     a.record()
-    for _ in range(10): step()
+    for _ in range(STEPS): step()
     b.record()
 ctx.synchronize()
-ms = a.elapsed_time(b) / 10
+ms = a.elapsed_time(b) / STEPS
 comp = n * (w + (2 * vs + 63) // 64)
 print("n=%d depth=%d vs=%d  %.3f ms  %.3f G branches/s  %.2f G compressions/s" % (n, depth, vs, ms, n / ms * 1e-6, comp / ms * 1e-6))
 
