@@ -7,6 +7,7 @@
 // batch.hip makes: the same branch kernel and the same check kernels run, only their descriptors and lanes
 // are written by kernels here instead of by host threads. Proofs of any other structure (including a `points`
 // component of another length, which the reference reads and ignores) take the general path.
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -475,8 +476,11 @@ static size_t fast_lane_bytes(size_t m) { return lane_layout(m).total; }
 
 // The launches alone, on stream `st`: one verdict byte per proof to d_status (device memory). The lanes and descriptors
 // live in kept buffer 0, which consecutive calls on one stream may share.
+// `beside` (optional): launches that depend on nothing but the caller's inputs; they are queued where the scalar checks
+// go, off the path that leads to the branch launch.
 static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, const uint64_t* d_base, const uint32_t* d_io,
-                       size_t mc, const CheckParams& CP, const uint32_t* d_mini, hipStream_t st, uint8_t* d_status) {
+                       size_t mc, const CheckParams& CP, const uint32_t* d_mini, hipStream_t st, uint8_t* d_status,
+                       const std::function<void(hipStream_t)>* beside = nullptr) {
     const Template& T = tmpl();
     int rc;
     const uint32_t m = (uint32_t)mc;
@@ -491,9 +495,14 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
     hipLaunchKernelGGL(vsample_kernel, dim3((m * (NL + 1) + 63) / 64), dim3(64), 0, st, d_blob, d_base, m, so, samples);
     F_TRY(hipGetLastError());
     // fork: the scalar checks need the samples (and the caller's inputs, which are ordered before this point on st).
-    // They go out first: short launches that do not fill the chip, which behind the branch launch would wait for its
-    // workgroups to drain (measured: five times their own duration).
+    // Which side is queued first is the host's choice, and the host is on the critical path: every launch call takes
+    // it 5-8 us, so whatever is queued behind the other side's eight calls starts 50 us late. The branch launch is
+    // the long pole (0.6 of 0.8 ms for 1,250 proofs), so the descriptors and the branch launch go out first, and the
+    // checks, short launches that do not fill the chip, find room beside it because its residency is capped (see
+    // launch_merkle_gather_groups; uncapped they waited for its workgroups to drain: five times their own duration,
+    // which is why they used to go first). STARKHIP_BATCH_ORDER=checks restores that order.
     const bool overlap = !(getenv("STARKHIP_BATCH_OVERLAP") && atoi(getenv("STARKHIP_BATCH_OVERLAP")) == 0);
+    const bool checks_first = getenv("STARKHIP_BATCH_ORDER") && !strcmp(getenv("STARKHIP_BATCH_ORDER"), "checks");
     hipStream_t sc = st;
     if (overlap) {
         // A plain stream of the context (ctx_aux_stream gives the rules). The fork event is recorded on st before side
@@ -506,54 +515,68 @@ static int fast_launch(stark_ctx* ctx, DevTemplate* D, const uint8_t* d_blob, co
         if (!D->ev_fork) F_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
         if (!D->ev_join) F_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
         F_TRY(hipEventRecord(D->ev_fork, st));
-        F_TRY(hipStreamWaitEvent(D->side, D->ev_fork, 0));
         sc = D->side;
     }
-    hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, sc, D->fri, d_blob, d_base, m, samples,
-                       (FriLane*)(d + o_fri));
-    hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, sc, D->con, d_blob, d_base, m, samples,
-                       (ConstraintLane*)(d + o_con));
-    hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, sc, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
-    F_TRY(hipGetLastError());
-    F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, sc));
-    F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
-                                  d + o_chk + (size_t)N_FRI * m, sc));
-    if (sc != st) F_TRY(hipEventRecord(D->ev_join, sc));
-    hipLaunchKernelGGL(vdesc_kernel, dim3((N_BRANCH + 255) / 256, m), dim3(256), 0, st, D->branches, d_base, m, samples,
-                       (uint64_t*)(d + o_rec), (uint64_t*)(d + o_root), (uint32_t*)(d + o_idx));
-    F_TRY(hipGetLastError());
     Buckets B = {};
     B.n = (uint32_t)T.buckets.size();
     if (B.n > 8) return STARK_ERR_UNSUPPORTED;
-    // all buckets of branches in one launch, deepest first (a launch per bucket would pay a tail each: the last
-    // wavefronts of a launch run their chain of compressions on an emptying chip); STARKHIP_BATCH_GATHER=split keeps
-    // the launch per bucket
-    const bool one_launch = !(getenv("STARKHIP_BATCH_GATHER") && !strcmp(getenv("STARKHIP_BATCH_GATHER"), "split"));
-    uint32_t order[8];
-    for (uint32_t b = 0; b < B.n; b++) order[b] = b;
-    std::stable_sort(order, order + B.n, [&](uint32_t x, uint32_t y) { return T.buckets[x].w > T.buckets[y].w; });
-    GatherGroups G = {};
-    G.n = B.n;
-    for (uint32_t b = 0; b < B.n; b++) {
-        const TBucket& k = T.buckets[b];
-        B.base[b] = k.base;
-        B.count[b] = k.count;
-        const size_t first = (size_t)k.base * m, n = (size_t)k.count * m;
-        if ((first + n) >> 32) return STARK_ERR_UNSUPPORTED;
-        if (!one_launch)
-            F_TRY(launch_merkle_gather(d_blob, (const uint64_t*)(d + o_rec) + first, k.vs, k.w, (const uint32_t*)(d + o_idx) + first,
-                                       (const uint64_t*)(d + o_root) + first, n, d + o_acc + first, st));
+    auto queue_checks = [&]() -> int {
+        if (sc != st) F_TRY(hipStreamWaitEvent(sc, D->ev_fork, 0));
+        if (beside) (*beside)(sc);
+        hipLaunchKernelGGL(vpack_fri_kernel, dim3((N_FRI + 255) / 256, m), dim3(256), 0, sc, D->fri, d_blob, d_base, m, samples,
+                           (FriLane*)(d + o_fri));
+        hipLaunchKernelGGL(vpack_con_kernel, dim3((SPOT + 127) / 128, m), dim3(128), 0, sc, D->con, d_blob, d_base, m, samples,
+                           (ConstraintLane*)(d + o_con));
+        hipLaunchKernelGGL(vkk_kernel, dim3((4 * m + 63) / 64), dim3(64), 0, sc, d_blob, d_base, m, T.merkle_root_off, d_io, d + o_kk);
+        F_TRY(hipGetLastError());
+        F_TRY(launch_fri_check((const FriLane*)(d + o_fri), (size_t)N_FRI * m, CP, d + o_chk, sc));
+        F_TRY(launch_constraint_check((const ConstraintLane*)(d + o_con), (size_t)SPOT * m, CP, d + o_kk, d_mini,
+                                      d + o_chk + (size_t)N_FRI * m, sc));
+        if (sc != st) F_TRY(hipEventRecord(D->ev_join, sc));
+        return STARK_OK;
+    };
+    auto queue_branches = [&]() -> int {
+        hipLaunchKernelGGL(vdesc_kernel, dim3((N_BRANCH + 255) / 256, m), dim3(256), 0, st, D->branches, d_base, m, samples,
+                           (uint64_t*)(d + o_rec), (uint64_t*)(d + o_root), (uint32_t*)(d + o_idx));
+        F_TRY(hipGetLastError());
+        // all buckets of branches in one launch, deepest first (a launch per bucket would pay a tail each: the last
+        // wavefronts of a launch run their chain of compressions on an emptying chip); STARKHIP_BATCH_GATHER=split keeps
+        // the launch per bucket
+        const bool one_launch = !(getenv("STARKHIP_BATCH_GATHER") && !strcmp(getenv("STARKHIP_BATCH_GATHER"), "split"));
+        uint32_t order[8];
+        for (uint32_t b = 0; b < B.n; b++) order[b] = b;
+        std::stable_sort(order, order + B.n, [&](uint32_t x, uint32_t y) { return T.buckets[x].w > T.buckets[y].w; });
+        GatherGroups G = {};
+        G.n = B.n;
+        for (uint32_t b = 0; b < B.n; b++) {
+            const TBucket& k = T.buckets[b];
+            B.base[b] = k.base;
+            B.count[b] = k.count;
+            const size_t first = (size_t)k.base * m, n = (size_t)k.count * m;
+            if ((first + n) >> 32) return STARK_ERR_UNSUPPORTED;
+            if (!one_launch)
+                F_TRY(launch_merkle_gather(d_blob, (const uint64_t*)(d + o_rec) + first, k.vs, k.w, (const uint32_t*)(d + o_idx) + first,
+                                           (const uint64_t*)(d + o_root) + first, n, d + o_acc + first, st));
+        }
+        for (uint32_t g = 0; g < B.n; g++) {
+            const TBucket& k = T.buckets[order[g]];
+            G.first[g] = (uint32_t)((size_t)k.base * m);
+            G.count[g] = (uint32_t)((size_t)k.count * m);
+            G.value_size[g] = k.vs;
+            G.num_witnesses[g] = k.w;
+        }
+        if (one_launch)
+            F_TRY(launch_merkle_gather_groups(d_blob, (const uint64_t*)(d + o_rec), (const uint32_t*)(d + o_idx),
+                                              (const uint64_t*)(d + o_root), d + o_acc, G, st));
+        return STARK_OK;
+    };
+    if (checks_first) {
+        if ((rc = queue_checks()) != STARK_OK) return rc;
+        if ((rc = queue_branches()) != STARK_OK) return rc;
+    } else {
+        if ((rc = queue_branches()) != STARK_OK) return rc;
+        if ((rc = queue_checks()) != STARK_OK) return rc;
     }
-    for (uint32_t g = 0; g < B.n; g++) {
-        const TBucket& k = T.buckets[order[g]];
-        G.first[g] = (uint32_t)((size_t)k.base * m);
-        G.count[g] = (uint32_t)((size_t)k.count * m);
-        G.value_size[g] = k.vs;
-        G.num_witnesses[g] = k.w;
-    }
-    if (one_launch)
-        F_TRY(launch_merkle_gather_groups(d_blob, (const uint64_t*)(d + o_rec), (const uint32_t*)(d + o_idx),
-                                          (const uint64_t*)(d + o_root), d + o_acc, G, st));
     if (sc != st) F_TRY(hipStreamWaitEvent(st, D->ev_join, 0));
     hipLaunchKernelGGL(vstatus_kernel, dim3(m), dim3(64), 0, st, m, B, d + o_acc, d + o_chk, d_status);
     F_TRY(hipGetLastError());
@@ -785,10 +808,14 @@ int fast_verify_resident_run(stark_ctx* ctx, const uint8_t* d_proofs, uint64_t s
     memcpy(a.l, inv_last_m1, 32);
     hipLaunchKernelGGL(vio_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, st, d_inputs, d_outputs, (const uint32_t*)nullptr,
                        (uint32_t)mc, a, d_io, (uint64_t)first, stride, d_base);
-    hipLaunchKernelGGL(vclassify_kernel, dim3((unsigned)mc), dim3(256), 0, st, d_proofs + stride * first, stride, D->words,
-                       D->n_words, d_ans);
     F_TRY(hipGetLastError());
-    if ((rc = fast_launch(ctx, D, d_proofs, d_base, d_io, mc, CP, d_mini, st, d_ans + up(mc))) != STARK_OK) return rc;
+    // the comparison of the structure words needs nothing from the sampling and nothing needs it before the verdicts are
+    // copied out: it goes beside the scalar checks (in front of the sampling it held the branch launch back by its 50 us)
+    const std::function<void(hipStream_t)> classify = [&](hipStream_t s) {
+        hipLaunchKernelGGL(vclassify_kernel, dim3((unsigned)mc), dim3(256), 0, s, d_proofs + stride * first, stride, D->words,
+                           D->n_words, d_ans);
+    };
+    if ((rc = fast_launch(ctx, D, d_proofs, d_base, d_io, mc, CP, d_mini, st, d_ans + up(mc), &classify)) != STARK_OK) return rc;
     // both answers in one copy
     std::vector<uint8_t> host(2 * up(mc));
     F_TRY(hipMemcpyAsync(host.data(), d_ans, 2 * up(mc), hipMemcpyDeviceToHost, st));
