@@ -91,10 +91,12 @@ def test_streaming_with_every_item_count_per_workgroup(monkeypatch):
         plain = _ctx(monkeypatch, False)
         x = _fill(plain, batch << log_n, 7 + batch)
         ref = _run(plain, x, batch, False, log_n=log_n)
+        ref_i = _run(plain, x, batch, True, log_n=log_n)
         plain.close()
         fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=1)
         try:
             assert torch.equal(_run(fast, x, batch, False, log_n=log_n), ref), (log_n, batch)
+            assert torch.equal(_run(fast, x, batch, True, in_place=True, log_n=log_n), ref_i), (log_n, batch, "inverse in place")
         finally:
             fast.close()
 

@@ -31,6 +31,7 @@ while time.time() < t_end:
         ctx = sv.default_context()
         x = torch.empty((batch * n, 8), dtype=torch.int32, device="cuda")
         ctx.check(ctx.lib.stark_fill_random_field_dev(ctx.handle, x.data_ptr(), batch * n, int(rng.integers(1 << 30)), None))
+        ctx.synchronize()  # the fill runs on the library's stream, the copy below on torch's
         inverse = bool(rng.integers(2))
         in_place = bool(rng.integers(2))
         y = x.clone() if in_place else torch.empty_like(x)
