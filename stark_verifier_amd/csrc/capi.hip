@@ -86,6 +86,10 @@ struct stark_ctx {
     // work counters of the streaming transform kernels: one block of 8 per stream that ever launched them (launches on
     // one stream run in order and zero the block in between; launches on different streams must not share one)
     std::vector<std::pair<hipStream_t, uint32_t*>> tickets;
+    uint32_t* ticket_pool = nullptr;  // TICKET_POOL blocks of 256 bytes, allocated with the context: the first streams
+                                      // that launch the streaming kernels take theirs from here, so that such a call
+                                      // allocates nothing (further streams get a block of their own by hipMalloc)
+    static constexpr size_t TICKET_POOL = 16;
     int n_cu = 0;  // compute units of the device
     unsigned copy_threads = 8;
 };
@@ -726,7 +730,8 @@ int run_plan(stark_ctx* ctx, NttPlan* plan, const uint32_t* d_in, uint32_t* d_ou
                 for (auto& t : ctx->tickets)
                     if (t.first == stream) tk = t.second;
                 if (!tk) {
-                    HIP_TRY(ctx, hipMalloc((void**)&tk, 256));
+                    if (ctx->tickets.size() < stark_ctx::TICKET_POOL) tk = ctx->ticket_pool + 64 * ctx->tickets.size();
+                    else HIP_TRY(ctx, hipMalloc((void**)&tk, 256));
                     ctx->tickets.emplace_back(stream, tk);
                 }
                 a.tickets = tk;
@@ -1192,6 +1197,11 @@ int stark_ctx_create(int device, stark_ctx** out) try {
         delete ctx;
         return STARK_ERR_HIP;
     }
+    if (hipMalloc((void**)&ctx->ticket_pool, 256 * stark_ctx::TICKET_POOL) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return STARK_ERR_NOMEM;
+    }
     const char* cb = getenv("STARKHIP_CHUNK_MB");
     if (cb && atoi(cb) > 0) ctx->chunk_bytes = (size_t)atoi(cb) << 20;
     const char* tb = getenv("STARKHIP_TABLE_MB");
@@ -1213,7 +1223,8 @@ void stark_ctx_destroy(stark_ctx* ctx) {
     for (auto& p : ctx->stage_a_tabs) free_plan(p.get());
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io) (void)hipFree(ctx->io);
-    for (auto& t : ctx->tickets) (void)hipFree(t.second);
+    for (size_t i = stark_ctx::TICKET_POOL; i < ctx->tickets.size(); i++) (void)hipFree(ctx->tickets[i].second);
+    if (ctx->ticket_pool) (void)hipFree(ctx->ticket_pool);
     for (stark_ctx::PinPair* P : {&ctx->up, &ctx->down})
         for (int i = 0; i < 2; i++) {
             if (P->busy[i]) (void)hipEventSynchronize(P->ev[i]);  // a transfer on a caller's stream

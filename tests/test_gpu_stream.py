@@ -129,3 +129,23 @@ def test_streaming_with_fewer_resident_workgroups_than_the_chip_holds(monkeypatc
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
         got = torch.load(out, weights_only=True)
     assert torch.equal(got, ref.cpu())
+
+
+def test_streaming_on_more_caller_streams_than_the_context_has_counter_blocks_ready(monkeypatch):
+    # the context holds sixteen counter blocks from its creation; the seventeenth and eighteenth stream get their own
+    log_n, batch = 16, 20
+    plain = _ctx(monkeypatch, False)
+    x = _fill(plain, batch << log_n, 5)
+    ref = _run(plain, x, batch, False, log_n=log_n)
+    plain.close()
+    fast = _ctx(monkeypatch, True, STARKHIP_STREAM_MIN=1)
+    try:
+        streams = [torch.cuda.Stream() for _ in range(18)]
+        torch.cuda.synchronize()
+        for k, s in enumerate(streams):   # one after the other: calls on one context share its intermediate buffer
+            assert torch.equal(_run(fast, x, batch, False, stream=s, log_n=log_n), ref), k
+        for k in (17, 0, 16):             # and again on streams that already have their block
+            assert torch.equal(_run(fast, x, batch, True, in_place=False, stream=streams[k], log_n=log_n),
+                               _run(fast, x, batch, True, log_n=log_n)), k
+    finally:
+        fast.close()
