@@ -566,7 +566,13 @@ struct SetupCache : CtxAttachment {
     Params P;
     CheckParams CP;
     uint32_t* d_mini = nullptr;
-    ~SetupCache() override { (void)hipFree(d_mini); }
+    uint32_t* d_pw = nullptr;    // CheckParams::pw / kext: powers of g2 and the constants' polynomial over them
+    uint32_t* d_kext = nullptr;
+    ~SetupCache() override {
+        (void)hipFree(d_mini);
+        (void)hipFree(d_pw);
+        (void)hipFree(d_kext);
+    }
 };
 constexpr int SETUP_SLOT = 2;
 
@@ -649,6 +655,18 @@ static int make_setup(stark_ctx* ctx, uint64_t num_steps, const uint32_t* round_
         for (size_t i = 0; i < P.mini_poly.size(); i++) hostfe::to_limbs(hostfe::canon(P.mini_poly[i]), &mp[8 * i]);
         if (hipMalloc((void**)&c->d_mini, mp.size() * 4) != hipSuccess) return STARK_ERR_NOMEM;
         if (hipMemcpy(c->d_mini, mp.data(), mp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return STARK_ERR_HIP;
+    }
+    // tables of the scalar checks (2 MiB + 16 KiB), built on the device by the arithmetic a lane would otherwise run
+    // for itself; STARKHIP_CHECK_TABLES=0 leaves them out (every lane then computes its own powers, as before)
+    if (!(getenv("STARKHIP_CHECK_TABLES") && atoi(getenv("STARKHIP_CHECK_TABLES")) == 0) && CP.precision == 65536u) {
+        hipStream_t st = (hipStream_t)stark_ctx_stream(ctx);
+        if (hipMalloc((void**)&c->d_pw, 32 * (size_t)CP.precision) != hipSuccess ||
+            hipMalloc((void**)&c->d_kext, 32 * (size_t)(CP.precision >> CP.log_skips2)) != hipSuccess)
+            return STARK_ERR_NOMEM;
+        if (launch_check_tables(CP, c->d_mini, c->d_pw, c->d_kext, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return STARK_ERR_HIP;
+        CP.pw = c->d_pw;
+        CP.kext = c->d_kext;
     }
     c->num_steps = num_steps;
     c->consts.assign(round_constants, round_constants + 8 * n_constants);

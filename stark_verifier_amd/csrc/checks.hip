@@ -98,7 +98,39 @@ __device__ __forceinline__ bool is_zero_t(const F29& x) {
     return o == 0;
 }
 
+__device__ __forceinline__ void store_canonical(uint32_t* o, const F29& x) {
+    const Fe v = f29_to_fe(x);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = v.l[i];
+}
+
+// k_of_x = constants_mini_polynomial(xk) (src/lib.rs:178), Horner from the top coefficient
+__device__ __forceinline__ F29 mini_poly_at(const uint32_t* __restrict__ mini_poly, uint32_t n_coeffs, const F29& xk) {
+    F29 kx = load_limbs(mini_poly + 8 * (n_coeffs - 1));
+#pragma unroll 1
+    for (int c = (int)n_coeffs - 2; c >= 0; c--) kx = add_t(mul_t(kx, xk), load_limbs(mini_poly + 8 * c));
+    return kx;
+}
+
 }  // namespace
+
+// The tables of CheckParams, by the arithmetic a lane would otherwise run itself: lane i < precision writes g2^i, lane
+// j < precision / skips2 also the mini polynomial at g2^(skips2 * j).
+__global__ void __launch_bounds__(256) check_tables_kernel(CheckParams P, const uint32_t* __restrict__ mini_poly,
+                                                           uint32_t* __restrict__ pw, uint32_t* __restrict__ kext) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.precision) return;
+    const F29 g2 = load_limbs(P.g2);
+    store_canonical(pw + 8 * (size_t)i, pow_t(g2, i, 32));
+    if (i < (P.precision >> P.log_skips2))
+        store_canonical(kext + 8 * (size_t)i, mini_poly_at(mini_poly, P.n_coeffs, norm(pow_t(g2, i << P.log_skips2, 32))));
+}
+
+hipError_t launch_check_tables(const CheckParams& P, const uint32_t* mini_poly, uint32_t* pw, uint32_t* kext, hipStream_t stream) {
+    if (P.precision == 0 || (P.precision & (P.precision - 1))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(check_tables_kernel, dim3((P.precision + 255) / 256), dim3(256), 0, stream, P, mini_poly, pw, kext);
+    return hipGetLastError();
+}
 
 __global__ void __launch_bounds__(256) fri_check_kernel(const FriLane* __restrict__ lanes, size_t n, CheckParams P,
                                                         uint8_t* __restrict__ status) {
@@ -108,12 +140,18 @@ __global__ void __launch_bounds__(256) fri_check_kernel(const FriLane* __restric
     const F29 r0 = load_be(L.rows[0]), r1 = load_be(L.rows[1]), r2 = load_be(L.rows[2]), r3 = load_be(L.rows[3]);
     const F29 col = load_be(L.col), special = load_be(L.special);
     const uint32_t layer = L.layer, y = L.y;
-    // root of unity of this layer: g2^(4^layer), of order 65536 / 4^layer (src/lib.rs:88-90)
-    F29 rou = load_limbs(P.g2);
+    // root of unity of this layer: g2^(4^layer), of order precision / 4^layer (src/lib.rs:88-90); x1 = rou^y (:74), so
+    // 1 / x1 = rou^(deg - y) = g2^((deg - y) * 4^layer): from the table when there is one and the exponent lies in it
+    const uint32_t deg = 2 * layer < 32 ? P.precision >> (2 * layer) : 0u;
+    F29 x1inv;
+    if (P.pw && deg > 0) {
+        x1inv = load_limbs(P.pw + 8 * (size_t)((((deg - y) & (deg - 1)) << (2 * layer)) & (P.precision - 1)));
+    } else {
+        F29 rou = load_limbs(P.g2);
 #pragma unroll 1
-    for (uint32_t k = 0; k < 2 * layer; k++) rou = mul_t(rou, rou);
-    const uint32_t deg = P.precision >> (2 * layer);
-    const F29 x1inv = pow_t(rou, (deg - y) & (deg - 1), 16);  // x1 = rou^y (:74)
+        for (uint32_t k = 0; k < 2 * layer; k++) rou = mul_t(rou, rou);
+        x1inv = pow_t(rou, (deg - y) & (deg - 1), 16);
+    }
     const F29 t = mul_t(special, x1inv);
     const F29 q = load_limbs(P.q4);
     const F29 A = add_t(r0, r2), B = sub_t(r0, r2), C = add_t(r1, r3), D = mul_t(sub_t(r1, r3), q);
@@ -138,19 +176,26 @@ __global__ void __launch_bounds__(256) constraint_check_kernel(const ConstraintL
     const F29 p = load_be(L.b1), d = load_be(L.b1 + 32), b = load_be(L.b1 + 64);
     const F29 pg = load_be(L.pg), l = load_be(L.l);
     const F29 one = f29_one();
-    const F29 x = pow_t(load_limbs(P.g2), L.pos, 16);  // :164
-    // x^skips2 on the way to x^num_steps (both powers of two)
-    F29 xs = x, xk = x;
+    // x = g2^pos (:164), xs = x^num_steps, kx = constants_mini_polynomial(x^skips2) (:178)
+    F29 x, xs, kx;
+    if (P.pw && P.kext && P.precision == 65536u) {  // (the square-and-multiply below reads 16 bits of pos)
+        const uint32_t pos = L.pos & (P.precision - 1);
+        x = load_limbs(P.pw + 8 * (size_t)pos);
+        xs = load_limbs(P.pw + 8 * (size_t)((pos << P.log_steps) & (P.precision - 1)));
+        kx = load_limbs(P.kext + 8 * (size_t)(pos & ((P.precision >> P.log_skips2) - 1)));
+    } else {
+        x = pow_t(load_limbs(P.g2), L.pos, 16);
+        // x^skips2 on the way to x^num_steps (both powers of two)
+        F29 xk = x;
+        xs = x;
 #pragma unroll 1
-    for (uint32_t k = 0; k < P.log_steps; k++) {
-        xs = mul_t(xs, xs);
-        if (k + 1 == P.log_skips2) xk = xs;
+        for (uint32_t k = 0; k < P.log_steps; k++) {
+            xs = mul_t(xs, xs);
+            if (k + 1 == P.log_skips2) xk = xs;
+        }
+        if (P.log_skips2 == 0) xk = x;
+        kx = mini_poly_at(mini_poly, P.n_coeffs, xk);
     }
-    if (P.log_skips2 == 0) xk = x;
-    // k_of_x = constants_mini_polynomial(x^skips2) (:178), Horner from the top coefficient
-    F29 kx = load_limbs(mini_poly + 8 * (P.n_coeffs - 1));
-#pragma unroll 1
-    for (int c = (int)P.n_coeffs - 2; c >= 0; c--) kx = add_t(mul_t(kx, xk), load_limbs(mini_poly + 8 * c));
     const F29 last = load_limbs(P.last_step);
     const F29 x_last = sub_t(x, last), x_1 = sub_t(x, one);
     uint8_t st = 0;

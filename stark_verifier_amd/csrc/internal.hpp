@@ -155,7 +155,16 @@ struct alignas(16) ConstraintLane {
 struct CheckParams {
     uint32_t g2[8], q4[8], last_step[8];  // canonical limbs
     uint32_t precision, log_steps, log_skips2, n_coeffs;
+    // Optional tables in device memory (launch_check_tables fills them; null: every lane computes its own powers):
+    // pw[i] = g2^i for i < precision, kext[j] = constants_mini_polynomial(g2^(skips2 * j)) for j < precision / skips2,
+    // 8 canonical limbs each. A sampled position's x, x^steps, x^skips2 and the inverse of a FRI point are all powers of
+    // g2 with exponents below precision, so a lane looks up what it would otherwise reach by square-and-multiply
+    // (24 multiplications) and by a Horner walk over the n_coeffs coefficients (63 multiplications and reductions).
+    const uint32_t* pw = nullptr;
+    const uint32_t* kext = nullptr;
 };
+// pw: precision x 8 dwords, kext: (precision >> log_skips2) x 8 dwords; P.pw / P.kext are ignored
+hipError_t launch_check_tables(const CheckParams& P, const uint32_t* mini_poly, uint32_t* pw, uint32_t* kext, hipStream_t stream);
 hipError_t launch_fri_check(const FriLane* lanes, size_t n, const CheckParams& P, uint8_t* status, hipStream_t stream);
 // kk: per proof CHECK_PROOF_BYTES: 4 x 32 bytes BLAKE2s(merkle_root || {1,2,3,4}), then 8 + 8 canonical limbs: the
 // instance's input and the slope (output - input) / (last_step - 1) of its boundary interpolant;

@@ -204,3 +204,21 @@ def test_malicious_proof_among_many_valid_ones_and_after_a_larger_batch(maliciou
         assert a.all() and not s.any()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_scalar_checks_without_their_tables_give_the_same_statuses(malicious_proofs, proof_bytes, monkeypatch, capfd):
+    """The check kernels look up g2^pos, x^steps and the constants' polynomial in tables that a context builds with its
+    first call for a parameter set; STARKHIP_CHECK_TABLES=0 makes every lane compute them itself (square-and-multiply and
+    a Horner walk, the form that follows src/lib.rs:164-178 literally). Both must give the reference's statuses."""
+    from stark_verifier_amd import _lib
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    blobs = [proof_bytes] + [m[1] for m in malicious_proofs] + [proof_bytes]
+    expect = [0] + [EXPECT[f[0]] for _, _, f, _ in malicious_proofs] + [0]
+    monkeypatch.setenv("STARKHIP_CHECK_TABLES", "0")
+    ctx = _lib.Context(0)
+    try:
+        _all_paths(blobs, expect, consts, output, ctx, monkeypatch, capfd, "per-lane powers")
+    finally:
+        ctx.close()
