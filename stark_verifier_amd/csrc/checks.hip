@@ -32,7 +32,9 @@ __device__ __forceinline__ F29 f29_one() {
 // canonical residue back in limb form: tight, and equal values have equal limbs
 __device__ __forceinline__ F29 norm(const F29& x) { return f29_from_fe(f29_to_fe(x)); }
 
-// 32 big-endian bytes (BigInt::from_bytes_be) -> canonical
+// 32 big-endian bytes (BigInt::from_bytes_be) -> tight limbs of the number as it stands (it may be p or more: the
+// arithmetic below is mod p whatever representative it starts from, every equality is decided on canonical residues,
+// and the one place where the reference's unreduced comparison shows, be_is_canonical, looks at the bytes itself)
 __device__ __forceinline__ F29 load_be(const uint8_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     const uint4 a = q[0], b = q[1];
@@ -45,7 +47,7 @@ __device__ __forceinline__ F29 load_be(const uint8_t* p) {
     x.l[2] = __builtin_bswap32(b.y);
     x.l[1] = __builtin_bswap32(b.z);
     x.l[0] = __builtin_bswap32(b.w);
-    return norm(f29_from_fe(x));
+    return f29_from_fe(x);
 }
 
 // Do these 32 big-endian bytes spell a number below p? (BigInt::from_bytes_be does not reduce.)

@@ -36,10 +36,10 @@ __device__ __forceinline__ F29 from_be_words(const uint4 a, const uint4 b) {
     x.l[2] = __builtin_bswap32(b.y);
     x.l[1] = __builtin_bswap32(b.z);
     x.l[0] = __builtin_bswap32(b.w);
-    return norm(f29_from_fe(x));
+    return f29_from_fe(x);  // tight limbs of the number as it stands (a hash read as a number may be p or more)
 }
 
-// 32 big-endian bytes at a 16-byte aligned address -> canonical
+// 32 big-endian bytes at a 16-byte aligned address -> tight
 __device__ __forceinline__ F29 load_be(const uint8_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     return from_be_words(q[0], q[1]);
