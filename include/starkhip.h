@@ -19,7 +19,9 @@
  *     mismatch is not an error here: it is reported per branch in `accept[]`; the binding
  *     re-creates the reference's panic / None from that.
  *   - Host-pointer entry points copy in, run on the context's stream, copy out, and return
- *     after the stream has drained. The `_dev` variants take device pointers (any allocator:
+ *     after the stream has drained. Buffers of 8 MiB and more in ordinary (pageable) memory are
+ *     copied through pinned staging buffers by host threads; a buffer that is pinned already
+ *     (hipHostMalloc, hipHostRegister) is handed to the copy engine as it is. The `_dev` variants take device pointers (any allocator:
  *     hipMalloc, a torch tensor's data_ptr) and a hipStream_t passed as void*; they only
  *     enqueue work and do not synchronise.
  *   - A context is bound to one device and is not thread-safe; use one per host thread.

@@ -139,6 +139,23 @@ void par_copy(char* dst, const char* src, size_t n, unsigned threads, stark_ctx:
 }
 }  // namespace
 
+// Is [p, p + n) host memory that the device can reach directly (hipHostMalloc, hipHostRegister, a pinned tensor)?
+// Such a buffer needs no staging: the copy engine reads or writes it at the link's rate and no host thread touches the
+// bytes. Both ends of the range are asked about; ordinary (pageable) memory is unknown to the runtime, which answers
+// with an error on some versions and with "unregistered" on others.
+static bool host_range_is_pinned(const void* p, size_t n) {
+    if (!p || n == 0) return false;
+    for (const char* q : {(const char*)p, (const char*)p + (n - 1)}) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
 // Before buf[b] is written again: wait for the transfer that last used it. Waiting here, not at the end of the call
 // that started the transfer, lets the caller prepare its next piece while the last one is still on the link.
 static hipError_t pin_acquire(stark_ctx::PinPair& P, unsigned b) {
@@ -148,9 +165,12 @@ static hipError_t pin_acquire(stark_ctx::PinPair& P, unsigned b) {
 }
 
 // Pageable host memory -> device through the two pinned upload buffers. On return `src` has been read completely;
-// the last one or two pieces may still be in flight on `stream`.
+// the last one or two pieces may still be in flight on `stream`. (A source that is pinned already goes as one
+// asynchronous copy and is still being read on return: every entry point drains its streams before it returns, and
+// the library's own temporaries are pageable.)
 hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t stream) {
-    if (n < STAGE_MIN || !ctx || !pin_ready(ctx, ctx->up)) return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
+    if (n < STAGE_MIN || !ctx || host_range_is_pinned(src, n) || !pin_ready(ctx, ctx->up))
+        return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream);
     stark_ctx::PinPair& P = ctx->up;
     hipError_t e = hipSuccess;
     for (size_t o = 0; o < n && e == hipSuccess; o += PIN_BYTES) {
@@ -168,7 +188,7 @@ hipError_t copy_h2d(stark_ctx* ctx, void* d_dst, const void* src, size_t n, hipS
 
 // Device -> pageable host memory through the two pinned download buffers; complete on return.
 hipError_t copy_d2h(stark_ctx* ctx, void* dst, const void* d_src, size_t n, hipStream_t stream) {
-    if (n < STAGE_MIN || !ctx || !pin_ready(ctx, ctx->down)) {
+    if (n < STAGE_MIN || !ctx || host_range_is_pinned(dst, n) || !pin_ready(ctx, ctx->down)) {
         hipError_t e = hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream);
         return e == hipSuccess ? hipStreamSynchronize(stream) : e;
     }

@@ -8,6 +8,7 @@ import pytest
 
 import oracle
 import proofio
+import synth
 import ref_verifier as rv
 from test_oracle import _oracle_hooks
 
@@ -484,3 +485,43 @@ def test_proofs_at_odd_offsets_take_the_fast_path_through_a_packed_copy(proof_by
     monkeypatch.setenv("STARKHIP_BATCH_PATH", "general")
     a2, s2 = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
     assert np.array_equal(a, a2) and np.array_equal(s, s2)
+
+
+@pytest.mark.gpu
+def test_pinned_caller_buffers_skip_the_staging_copy_and_give_the_same_answer(proof_bytes):
+    """A caller's buffer that is pinned already (hipHostMalloc, a pinned tensor) is handed to the copy engine as it is,
+    not copied through the library's staging buffers: same verdicts from the batch verifier, same transform from the
+    host-buffer NTT entry point (both above the 8 MiB from which pageable buffers are staged)."""
+    import torch
+    from stark_verifier_amd import _lib, batch, fft
+    from stark_verifier_amd.fft import _limbs, _ptr, MODULUS
+    consts = rv.mimc_constants()
+    output = rv.mimc(3, 8192, consts)
+    v = _variants(proof_bytes)
+    names = ["good", "witness_bit", "good", "trace_value_bit", "points_bit", "root2_bit", "good", "column_value_bit"]
+    blobs = [v[k] for k in names] * 4   # 32 proofs, 18 MB
+    ref_a, ref_s = batch.verify_mimc_batch(blobs, 3, 8192, consts, output)
+    ctx = _lib.default_context()
+    total = sum(map(len, blobs))
+    pinned = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    pinned.numpy()[:] = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    offsets = np.zeros(len(blobs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
+    rcs = np.ascontiguousarray(np.concatenate([_limbs(c % MODULUS) for c in consts]))
+    acc = np.zeros(len(blobs), dtype=np.uint8)
+    st = np.zeros(len(blobs), dtype=np.uint8)
+    i_, o_ = _limbs(3), _limbs(output % MODULUS)
+    for _ in range(2):
+        ctx.check(ctx.lib.stark_mimc_verify_batch(ctx.handle, pinned.data_ptr(), offsets.ctypes.data, len(blobs), _ptr(i_), 8192,
+                                                  rcs.ctypes.data, 64, _ptr(o_), acc.ctypes.data, st.ctypes.data))
+        assert np.array_equal(acc, ref_a) and np.array_equal(st, ref_s)
+    # host-buffer transform: 8 polynomials of 2^16 points = 16 MiB each way, pinned in and out
+    log_n, B = 16, 8
+    w = pow(7, (oracle.P - 1) >> log_n, oracle.P)
+    x = synth.field_elements(77, B << log_n).reshape(B, 1 << log_n, 8)
+    ref = fft.ntt_batch(x, w)
+    buf = torch.empty(x.size, dtype=torch.int32, pin_memory=True)   # the host entry point works in place
+    buf.numpy()[:] = x.reshape(-1).view(np.int32)
+    w_ = _limbs(w)
+    ctx.check(ctx.lib.stark_ntt_batch(ctx.handle, buf.data_ptr(), log_n, B, _ptr(w_), 0))
+    assert np.array_equal(buf.numpy().view(np.uint32).reshape(x.shape), ref)
