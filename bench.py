@@ -413,6 +413,7 @@ def main():
                               (case_t[0][lo:hi], case_t[1][lo:hi], case_t[2][:, lo:hi], case_t[3][lo:hi].view(np.int32)))
             troot = d["root"] if same else torch.from_numpy(case_t[4]).to(device)
             tacc = torch.zeros(m, dtype=torch.uint8, device=device)
+            hacc = torch.empty(m, dtype=torch.uint8, pin_memory=True)   # verdicts land in pinned host memory
             got = {}
 
             def step():
@@ -421,8 +422,10 @@ def main():
                 if world > 1:
                     got["all"] = sharding.gather_accept_bits(tacc, tot, device=coll_device)
                 else:
-                    got["all"] = tacc.cpu().numpy()
-            return step, (lambda: bool(np.array_equal(got["all"], expect_t if world > 1 else expect_t[lo:hi]))), (tv, ts, tw, ti, tacc)
+                    hacc.copy_(tacc, non_blocking=True)
+                    tstream.synchronize()
+                    got["all"] = hacc.numpy()
+            return step, (lambda: bool(np.array_equal(got["all"], expect_t if world > 1 else expect_t[lo:hi]))), (tv, ts, tw, ti, tacc, hacc)
 
         lo_t, hi_t = sharding.shard_range(tot, rank, world)
         step_t, check_t, keep_t = strong_slice(lo_t, hi_t)
@@ -527,7 +530,7 @@ def main():
                 "scaling": "strong", "value": tot * K / dt_t, "unit": "branches/s", "ms_per_step": dt_t / K * 1e3,
                 "branches_total": tot, "branches_this_rank": mine,
                 "verdict_delivery": "all_gather of the accept bytes over RCCL inside the timed region" if world > 1
-                                    else "device-to-host copy of the accept bytes inside the timed region (one rank: nothing to gather)",
+                                    else "device-to-host copy of the accept bytes into pinned host memory inside the timed region (one rank: nothing to gather)",
                 "accept_vector_as_constructed": strong_ok,
             }
             if slices:
