@@ -142,6 +142,12 @@ def _all_paths(blobs, expect, consts, output, ctx, monkeypatch, capfd, label):
     a, s = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs, ctx=ctx)
     check("fast, checks behind the branch launch", a, s)
     monkeypatch.delenv("STARKHIP_BATCH_OVERLAP")
+    monkeypatch.setenv("STARKHIP_BATCH_ORDER", "checks")
+    a, s = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs, ctx=ctx)
+    check("fast, checks queued ahead of the branch launch", a, s)
+    a, s = batch.verify_mimc_batch_dev(d.data_ptr(), size, n, d_in.data_ptr(), 8192, consts, d_out.data_ptr(), ctx=ctx)
+    check("resident, checks queued ahead of the branch launch", a, s)
+    monkeypatch.delenv("STARKHIP_BATCH_ORDER")
     monkeypatch.setenv("STARKHIP_PIECE_MB", "1")
     a, s = batch.verify_mimc_batch_io(blobs, ins, 8192, consts, outs, ctx=ctx)
     check("fast, one proof per piece", a, s)
