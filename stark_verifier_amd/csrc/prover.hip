@@ -92,7 +92,10 @@ trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, co
              Dev D) {
     const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= n) return;
-    // the value is carried both ways: canonical 8 x 32-bit for the store, nine limbs for the arithmetic
+    // The value is carried both ways: canonical 8 x 32-bit for the store, nine tight limbs for the arithmetic (the limbs
+    // the canonicalisation passes through anyway). This loop is a wavefront alone on its SIMD, which is served once in
+    // four cycles whatever it issues, so its time is its instruction count: hence the squaring routine and no
+    // re-conversion of the stored value.
     Fe xe = f29_to_fe(load_limbs(inputs + 8 * (size_t)pr));
     F29 x = f29_from_fe(xe);
     const F29 inp = x;
@@ -101,8 +104,9 @@ trace_kernel(const uint32_t* __restrict__ inputs, uint32_t n, uint32_t steps, co
     for (uint32_t i = 0; i + 1 < steps; i++) {
         fe_store(row + 8 * (size_t)i, xe);
         const F29 c = load_limbs(consts + 8 * (i & cmask));
-        xe = f29_to_fe(f29_add(mul_t(mul_t(x, x), x), c));
-        x = f29_from_fe(xe);
+        F29 xt;
+        xe = f29_to_fe_keep(f29_add(mul_t(f29_sqr(x), x), c), xt);
+        x = xt;
     }
     fe_store(row + 8 * (size_t)(steps - 1), xe);
     fe_store(outputs + 8 * (size_t)pr, xe);
