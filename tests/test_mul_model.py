@@ -164,3 +164,56 @@ def test_split_product_columns_fit_64_bits_and_result_is_tight(wide):
         bv = rng.choice([0, 1, P - 1, P - 2, rng.getrandbits(256) % P])
         o = f29_mul_split(chk, a, limbs(bv), limbs(bv * shift % P), wide)
         assert val(o) % P == val(a) * bv % P and is_tight(o), (a, bv)
+
+
+def f29_sqr(chk, a):
+    """The squaring routine of field29.cuh (wide limbs in low columns 0..2): every pair i < j once against the doubled
+    limb d_i = 2 a_i, the squares a_i^2 where the column index is even."""
+    d = [2 * x for x in a]
+    assert all(x < 2**32 for x in d[:8])
+    wide = 2
+
+    def column(acc, k):
+        for i in range(max(0, k - 8), 9):
+            j = k - i
+            if i < j <= 8:
+                acc = chk(acc + d[i] * a[j])
+            elif i == j:
+                acc = chk(acc + a[i] * a[i])
+        return acc
+
+    th = [0] * 9
+    acc = 0
+    for k in range(9, 17):
+        acc = column(acc, k)
+        th[k - 9], acc = leave(acc, wide & 1)
+    th[8] = acc
+    assert th[8] < 2**32
+    r = [0] * 9
+    acc = 0
+    for k in range(9):
+        acc = column(acc, k)
+        acc = chk(acc + th[k] * FOLD0)
+        if k >= 1:
+            acc = chk(acc + th[k - 1] * FOLD1)
+        r[k], acc = leave(acc, (wide & 2) and k < 3)
+    acc = chk(acc + th[8] * FOLD1)
+    return second_fold(chk, r, acc)
+
+
+def test_squaring_routine_equals_the_product_and_keeps_its_bounds():
+    # inputs: what the prover's trace walk feeds it, the limbs f29_tighten leaves (limbs 0..7 below 2^29, limb 8 below
+    # 2^24 + 8), and tight values as f29_mul returns them (limb 3 up to 31 above)
+    chk = Acc()
+    worst = [MASK, MASK, MASK, MASK + 31, MASK, MASK, MASK, MASK, 2**24 + 7]
+    o = f29_sqr(chk, worst)
+    assert val(o) % P == val(worst) ** 2 % P and is_tight(o)
+    assert chk.peak < 2**63                                          # far from the accumulator's end: both operands are tight
+    rng = random.Random(21)
+    for _ in range(3000):
+        a = [rng.choice([0, 1, MASK, MASK - 1, rng.getrandbits(29)]) for _ in range(8)] + [rng.choice([0, 2**24 + 7, rng.getrandbits(24)])]
+        if rng.random() < 0.3:
+            a[3] += 31
+        o = f29_sqr(chk, a)
+        ref = f29_mul(Acc(), a, a, 2)
+        assert o == ref and val(o) % P == val(a) ** 2 % P and is_tight(o), a
